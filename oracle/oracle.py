@@ -1,0 +1,213 @@
+"""TEST INFRASTRUCTURE ONLY.  ctypes loaders for
+
+  * ``Oracle``    -- oracle/_build/libyart_oracle.so, the CPU restatement of the
+                     reference intersection path (oracle/cpu_ref.cpp);
+  * ``Reference`` -- oracle/_ref/libyart_ref.so, the REAL reference compiled from
+                     /root/reference by oracle/Makefile (authoring container only;
+                     the GPU box gets the prebuilt file).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The product package (yart_amd/) never does.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "_build", "libyart_oracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libyart_ref.so")
+REF_FMA_SO = os.path.join(HERE, "_ref", "libyart_ref_fma.so")
+
+c_sz = ctypes.c_size_t
+c_vp = ctypes.c_void_p
+
+NODE_DTYPE = np.dtype([("bounds", np.float32, 6), ("offset", np.uint32),
+                       ("numTriangles", np.uint8), ("splitAxis", np.uint8),
+                       ("pad", np.uint8, 2)])
+TRIACCEL_DTYPE = np.dtype([("n_u", np.float32), ("n_v", np.float32), ("n_d", np.float32), ("k", np.int32),
+                           ("b_u", np.float32), ("b_v", np.float32), ("b_d", np.float32), ("triIdx", np.int32),
+                           ("c_u", np.float32), ("c_v", np.float32), ("c_d", np.float32), ("meshIdx", np.int32)])
+HIT_DTYPE = np.dtype([("t", np.float32), ("u", np.float32), ("v", np.float32), ("prim", np.int32)])
+REFHIT_DTYPE = np.dtype([("hit", np.int32), ("t", np.float32), ("u", np.float32), ("v", np.float32),
+                         ("prim", np.int32), ("ambiguous", np.int32),
+                         ("normal", np.float32, 3), ("shadingNormal", np.float32, 3)])
+assert NODE_DTYPE.itemsize == 32 and TRIACCEL_DTYPE.itemsize == 48
+assert HIT_DTYPE.itemsize == 16 and REFHIT_DTYPE.itemsize == 48
+
+
+def _p(a):
+    return a.ctypes.data_as(c_vp) if a is not None else None
+
+
+def build_oracle(force=False):
+    """Compile the restatement (gcc only; works here and on the GPU box)."""
+    if force or not os.path.exists(ORACLE_SO) or \
+            os.path.getmtime(ORACLE_SO) < os.path.getmtime(os.path.join(HERE, "cpu_ref.cpp")):
+        subprocess.check_call(["make", "-C", HERE, "oracle"], stdout=subprocess.DEVNULL)
+    return ORACLE_SO
+
+
+def build_reference():
+    """Compile the real reference; only where /root/reference exists."""
+    if not os.path.isdir("/root/reference"):
+        return None
+    subprocess.check_call(["make", "-C", HERE, "ref"], stdout=subprocess.DEVNULL)
+    return REF_SO
+
+
+def _scene_args(verts, tris, spheres):
+    verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
+    tris = np.ascontiguousarray(tris, np.int32).reshape(-1, 5)
+    spheres = np.ascontiguousarray(spheres, np.float32).reshape(-1, 4)
+    return verts, tris, spheres
+
+
+class Oracle:
+    """CPU restatement (cpu_ref.cpp)."""
+
+    def __init__(self, verts, tris, spheres):
+        build_oracle()
+        self.lib = L = ctypes.CDLL(ORACLE_SO)
+        L.orc_scene_create.restype = c_vp
+        L.orc_scene_create.argtypes = [c_vp, c_sz, c_vp, c_sz, c_vp, c_sz]
+        L.orc_scene_destroy.argtypes = [c_vp]
+        L.orc_num_nodes.restype = c_sz
+        L.orc_num_nodes.argtypes = [c_vp]
+        L.orc_get_nodes.argtypes = [c_vp, c_vp]
+        L.orc_get_triaccel.argtypes = [c_vp, c_vp]
+        L.orc_get_leaf_order.argtypes = [c_vp, c_vp]
+        L.orc_intersect.argtypes = [c_vp, c_vp, c_sz, c_vp, c_vp, ctypes.c_int, ctypes.c_int]
+        L.orc_intersect_shadow.argtypes = [c_vp, c_vp, c_sz, c_vp, c_vp, ctypes.c_int, ctypes.c_int]
+        self.verts, self.tris, self.spheres = _scene_args(verts, tris, spheres)
+        self.h = L.orc_scene_create(_p(self.verts), len(self.verts), _p(self.tris), len(self.tris),
+                                    _p(self.spheres), len(self.spheres))
+        if not self.h:
+            raise ValueError("oracle: bad scene")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.orc_scene_destroy(self.h)
+            self.h = None
+
+    def nodes(self):
+        out = np.zeros(self.lib.orc_num_nodes(self.h), NODE_DTYPE)
+        self.lib.orc_get_nodes(self.h, _p(out))
+        return out
+
+    def triaccel(self):
+        out = np.zeros(len(self.tris), TRIACCEL_DTYPE)
+        self.lib.orc_get_triaccel(self.h, _p(out))
+        return out
+
+    def leaf_order(self):
+        out = np.zeros(len(self.tris), np.uint32)
+        self.lib.orc_get_leaf_order(self.h, _p(out))
+        return out
+
+    def intersect(self, rays, mode=0, counts=False, nthreads=8):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        hits = np.zeros(len(rays), HIT_DTYPE)
+        cnt = np.zeros((len(rays), 3), np.uint32) if counts else None
+        self.lib.orc_intersect(self.h, _p(rays), len(rays), _p(hits), _p(cnt), mode, nthreads)
+        return (hits, cnt) if counts else hits
+
+    def intersect_shadow(self, rays, mode=0, counts=False, nthreads=8):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        occ = np.zeros(len(rays), np.uint8)
+        cnt = np.zeros((len(rays), 3), np.uint32) if counts else None
+        self.lib.orc_intersect_shadow(self.h, _p(rays), len(rays), _p(occ), _p(cnt), mode, nthreads)
+        return (occ, cnt) if counts else occ
+
+
+class Reference:
+    """The real reference (ref_shim.cpp around /root/reference)."""
+
+    def __init__(self, verts, tris, spheres, gen_normals=True, so=None):
+        so = so or REF_SO
+        if not os.path.exists(so):
+            raise FileNotFoundError(so)
+        self.lib = L = ctypes.CDLL(so)
+        L.ref_scene_create.restype = c_vp
+        L.ref_scene_create.argtypes = [c_vp, c_sz, c_vp, c_sz, c_vp, c_sz, ctypes.c_int]
+        L.ref_scene_destroy.argtypes = [c_vp]
+        L.ref_num_nodes.restype = c_sz
+        L.ref_num_nodes.argtypes = [c_vp]
+        L.ref_get_nodes.argtypes = [c_vp, c_vp]
+        L.ref_get_triaccel.argtypes = [c_vp, c_vp]
+        L.ref_intersect.argtypes = [c_vp, c_vp, c_sz, c_vp, ctypes.c_int]
+        L.ref_intersect_shadow.argtypes = [c_vp, c_vp, c_sz, c_vp, ctypes.c_int]
+        L.ref_intersect_throughput.argtypes = [c_vp, c_vp, c_sz, c_vp, ctypes.c_int]
+        self.verts, self.tris, self.spheres = _scene_args(verts, tris, spheres)
+        self.h = L.ref_scene_create(_p(self.verts), len(self.verts), _p(self.tris), len(self.tris),
+                                    _p(self.spheres), len(self.spheres), 1 if gen_normals else 0)
+        if not self.h:
+            raise ValueError("reference: bad scene")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ref_scene_destroy(self.h)
+            self.h = None
+
+    def nodes(self):
+        out = np.zeros(self.lib.ref_num_nodes(self.h), NODE_DTYPE)
+        self.lib.ref_get_nodes(self.h, _p(out))
+        return out
+
+    def triaccel(self):
+        out = np.zeros(len(self.tris), TRIACCEL_DTYPE)
+        self.lib.ref_get_triaccel(self.h, _p(out))
+        return out
+
+    def intersect(self, rays, nthreads=8):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        out = np.zeros(len(rays), REFHIT_DTYPE)
+        self.lib.ref_intersect(self.h, _p(rays), len(rays), _p(out), nthreads)
+        return out
+
+    def intersect_shadow(self, rays, nthreads=8):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        out = np.zeros(len(rays), np.uint8)
+        self.lib.ref_intersect_shadow(self.h, _p(rays), len(rays), _p(out), nthreads)
+        return out
+
+    def throughput(self, rays, nthreads=8):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        out = np.zeros(len(rays), np.float32)
+        self.lib.ref_intersect_throughput(self.h, _p(rays), len(rays), _p(out), nthreads)
+        return out
+
+
+def reference_cornell(so=None):
+    """Geometry of the reference's Scene::makeCornellBox (src/scene.cpp:4-157)."""
+    L = ctypes.CDLL(so or REF_SO)
+    nv, nt, ns = c_sz(), c_sz(), c_sz()
+    L.ref_cornell(None, ctypes.byref(nv), None, ctypes.byref(nt), None, ctypes.byref(ns))
+    verts = np.zeros((nv.value, 3), np.float32)
+    tris = np.zeros((nt.value, 5), np.int32)
+    sph = np.zeros((ns.value, 4), np.float32)
+    L.ref_cornell(_p(verts), ctypes.byref(nv), _p(tris), ctypes.byref(nt), _p(sph), ctypes.byref(ns))
+    return verts, tris, sph
+
+
+def reference_camera_rays(pos, direction, width, height, fov, xy, so=None):
+    """Camera::sample (include/camera.h:24-31) of the real reference."""
+    L = ctypes.CDLL(so or REF_SO)
+    L.ref_camera_rays.argtypes = [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, c_vp, c_sz, c_vp]
+    pos = np.ascontiguousarray(pos, np.float32)
+    direction = np.ascontiguousarray(direction, np.float32)
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    rays = np.zeros((len(xy), 8), np.float32)
+    L.ref_camera_rays(_p(pos), _p(direction), width, height, fov, _p(xy), len(xy), _p(rays))
+    return rays
+
+
+def reference_uniform_sphere(u12, so=None):
+    """uniformSphereSample (include/qmc.h:82-94) of the real reference."""
+    L = ctypes.CDLL(so or REF_SO)
+    L.ref_uniform_sphere.argtypes = [c_vp, c_sz, c_vp]
+    u12 = np.ascontiguousarray(u12, np.float32).reshape(-1, 2)
+    out = np.zeros((len(u12), 3), np.float32)
+    L.ref_uniform_sphere(_p(u12), len(u12), _p(out))
+    return out

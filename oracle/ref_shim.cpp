@@ -1,0 +1,368 @@
+// TEST INFRASTRUCTURE ONLY -- not part of the product path.
+//
+// ref_shim.cpp: thin C-ABI wrapper that compiles the REAL reference
+// (elaic/yart, read-only at /root/reference) from the sources where they lie
+// and exposes its Scene::intersect / Scene::intersectShadow / BvhAccel to
+// Python (ctypes).  Built only in the authoring container by oracle/Makefile
+// into oracle/_ref/libyart_ref.so (git-ignored; travels to the GPU box as a
+// built binary).  Uses:
+//   * oracle/make_golden.py  -> golden vectors under tests/golden/
+//   * tests/                 -> pin the CPU restatement (oracle/cpu_ref.cpp)
+//   * bench.py cpu_baseline  -> kind "reference"
+//
+// No reference source is copied here: this file only #includes the reference
+// headers/sources by path and calls their public entry points.  Private
+// members are reached with the usual test-only `#define private public`
+// (needed because Scene::preprocess() overflows in loadTriaccel8 when
+// triangleCount % 8 == 0 -- SURVEY.md 8c -- so the BvhAccel is constructed
+// directly, exactly as preprocess() does at include/scene.h:73).
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <memory>
+#include <random>
+#include <string>
+#include <thread>
+#include <tuple>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+#include <immintrin.h>
+
+#define private public
+#include "scene.h"
+#include "camera.h"
+// FlattenedBvhNode is only defined inside the .cpp (src/bvhaccel.cpp:64), so
+// this TU *is* the bvhaccel translation unit of the reference build.
+#include "../src/bvhaccel.cpp"
+#undef private
+
+namespace {
+
+struct RefScene {
+    std::unique_ptr<Scene> scene;
+    // per mesh: the mesh's Bsdf* -> mesh index (each mesh gets its own object)
+    std::unordered_map<const Bsdf*, int32_t> bsdfToMesh;
+    // per mesh: positions (in leaf order) of that mesh's TriAccel records
+    std::vector<std::vector<int32_t>> meshLeafSlots;
+    // per sphere: the fake AreaLight* tag identifies the sphere
+    size_t numSpheres = 0;
+    size_t numTriangles = 0;
+};
+
+struct NodeOut {            // normalised 32-byte dump of FlattenedBvhNode
+    float bounds[6];
+    uint32_t offset;        // childOffset | triangleOffset
+    uint8_t numTriangles;   // 0 for interior nodes (uninitialised in the reference)
+    uint8_t splitAxis;      // 0,1,2 ; 3 = leaf
+    uint8_t pad[2];
+};
+static_assert(sizeof(NodeOut) == 32, "NodeOut must be 32 bytes");
+
+struct HitOut {
+    int32_t hit;            // return value of Scene::intersect
+    float t, u, v;
+    int32_t prim;           // >=0: leaf-order TriAccel index; -(i+2): sphere i; -1 miss
+    int32_t ambiguous;      // >1 if several triangles of the mesh reproduce (t,u,v) bit-for-bit
+    float normal[3];
+    float shadingNormal[3];
+};
+
+// A tag that is never dereferenced: Scene::intersect only copies getLight()
+// into RayHitInfo::areaLight (include/sphere.h:83).
+AreaLight* sphereTag(size_t i) { return reinterpret_cast<AreaLight*>(uintptr_t(0x1000 + 16 * i)); }
+
+RefScene* buildScene(const float* verts, size_t nVerts, const int32_t* tris, size_t nTris,
+                     const float* spheres, size_t nSpheres, int genNormals)
+{
+    auto rs = new RefScene();
+    std::vector<TriangleMesh> meshes;
+    // group triangles by meshId (must be contiguous, ascending from 0)
+    size_t i = 0;
+    while (i < nTris) {
+        int32_t mid = tris[i * 5 + 3];
+        size_t j = i;
+        int32_t vmin = std::numeric_limits<int32_t>::max(), vmax = -1;
+        while (j < nTris && tris[j * 5 + 3] == mid) {
+            for (int c = 0; c < 3; ++c) {
+                vmin = std::min(vmin, tris[j * 5 + c]);
+                vmax = std::max(vmax, tris[j * 5 + c]);
+            }
+            ++j;
+        }
+        if (mid != (int32_t)meshes.size() || vmax >= (int64_t)nVerts) {
+            fprintf(stderr, "ref_shim: mesh ids must be contiguous from 0 / bad vertex index\n");
+            delete rs;
+            return nullptr;
+        }
+        std::vector<Vector3f> v;
+        v.reserve(vmax - vmin + 1);
+        for (int32_t k = vmin; k <= vmax; ++k)
+            v.emplace_back(verts[k * 3 + 0], verts[k * 3 + 1], verts[k * 3 + 2]);
+        std::vector<Triangle> t;
+        t.reserve(j - i);
+        for (size_t k = i; k < j; ++k) {
+            if (tris[k * 5 + 4] != (int32_t)(k - i)) {
+                fprintf(stderr, "ref_shim: triIds must count from 0 inside each mesh\n");
+                delete rs;
+                return nullptr;
+            }
+            t.emplace_back(tris[k * 5 + 0] - vmin, tris[k * 5 + 1] - vmin, tris[k * 5 + 2] - vmin);
+        }
+        auto bsdf = std::make_shared<Lambertian>(Spectrum(0.5f, 0.5f, 0.5f));
+        if (genNormals) {
+            meshes.emplace_back(v, t, bsdf);     // include/triangle.h:76 (generates vertex normals)
+        } else {
+            std::vector<Vector3f> n(v.size(), Vector3f(0.0f, 0.0f, 1.0f));
+            meshes.emplace_back(v, n, t, bsdf);  // include/triangle.h:113
+        }
+        i = j;
+    }
+
+    std::vector<std::shared_ptr<Shape>> shapes;
+    for (size_t s = 0; s < nSpheres; ++s) {
+        auto sp = std::make_shared<Sphere>(spheres[s * 4 + 3],
+            Vector3f(spheres[s * 4 + 0], spheres[s * 4 + 1], spheres[s * 4 + 2]),
+            Spectrum(0.5f, 0.5f, 0.5f), Bxdf::Diff);
+        sp->setLight(sphereTag(s));
+        shapes.push_back(sp);
+    }
+    std::vector<std::shared_ptr<Light>> lights;
+
+    rs->scene = std::make_unique<Scene>(meshes, shapes, lights);
+    // what Scene::preprocess() does at include/scene.h:73, minus the TriAccel8 path
+    rs->scene->accel_ = std::make_shared<BvhAccel>(*rs->scene);
+    rs->numSpheres = nSpheres;
+    rs->numTriangles = nTris;
+
+    const auto& ms = rs->scene->meshes_;
+    rs->meshLeafSlots.resize(ms.size());
+    for (size_t m = 0; m < ms.size(); ++m) rs->bsdfToMesh[ms[m].getBsdf()] = (int32_t)m;
+    const TriAccel* ta = rs->scene->accel_->triangles_;
+    for (size_t k = 0; k < nTris; ++k) rs->meshLeafSlots[ta[k].meshIdx].push_back((int32_t)k);
+    return rs;
+}
+
+template <class F>
+void parallelFor(size_t n, int nthreads, F&& f)
+{
+    if (nthreads <= 1) { f(0, n); return; }
+    std::vector<std::thread> th;
+    std::atomic<size_t> next{0};
+    const size_t chunk = 1024;
+    for (int t = 0; t < nthreads; ++t) {
+        th.emplace_back([&]() {
+            for (;;) {
+                size_t b = next.fetch_add(chunk);
+                if (b >= n) break;
+                f(b, std::min(n, b + chunk));
+            }
+        });
+    }
+    for (auto& t : th) t.join();
+}
+
+Ray makeRay(const float* r)
+{
+    Ray ray(Vector3f(r[0], r[1], r[2]), Vector3f(r[4], r[5], r[6]));
+    ray.minT = r[3];
+    ray.maxT = r[7];
+    return ray;
+}
+
+} // namespace
+
+extern "C" {
+
+void* ref_scene_create(const float* verts, size_t nVerts, const int32_t* tris, size_t nTris,
+                       const float* spheres, size_t nSpheres, int genNormals)
+{
+    return buildScene(verts, nVerts, tris, nTris, spheres, nSpheres, genNormals);
+}
+
+void ref_scene_destroy(void* h) { delete static_cast<RefScene*>(h); }
+
+size_t ref_num_nodes(void* h)
+{
+    return static_cast<RefScene*>(h)->scene->accel_->optimizedAccel_.size();
+}
+
+void ref_get_nodes(void* h, void* out)
+{
+    const auto& nodes = static_cast<RefScene*>(h)->scene->accel_->optimizedAccel_;
+    auto* o = static_cast<NodeOut*>(out);
+    for (size_t i = 0; i < nodes.size(); ++i) {
+        const auto& n = nodes[i];
+        NodeOut r;
+        std::memset(&r, 0, sizeof r);
+        r.bounds[0] = n.bounds.min.x; r.bounds[1] = n.bounds.min.y; r.bounds[2] = n.bounds.min.z;
+        r.bounds[3] = n.bounds.max.x; r.bounds[4] = n.bounds.max.y; r.bounds[5] = n.bounds.max.z;
+        r.splitAxis = (uint8_t)n.splitAxis;
+        r.offset = n.childOffset;
+        r.numTriangles = (n.splitAxis == SplitAxis::None) ? n.numTriangles : 0;
+        o[i] = r;
+    }
+}
+
+void ref_get_triaccel(void* h, void* out)
+{
+    auto* rs = static_cast<RefScene*>(h);
+    static_assert(sizeof(TriAccel) == 48, "TriAccel must be 48 bytes");
+    std::memcpy(out, rs->scene->accel_->triangles_, rs->numTriangles * sizeof(TriAccel));
+}
+
+// Scene::intersect (include/scene.h:136) on every ray; the primitive identity,
+// which the reference API does not return, is recovered from the borrowed
+// pointers in RayHitInfo (sphere: areaLight tag; triangle: bsdf -> mesh) and,
+// inside the mesh, by replaying the reference's own public
+// intersect(TriAccel, Ray, RayHitInfo*) (include/triaccel.h:170) until one
+// record reproduces (t,u,v) bit-for-bit.
+void ref_intersect(void* h, const float* rays, size_t n, void* out, int nthreads)
+{
+    auto* rs = static_cast<RefScene*>(h);
+    auto* o = static_cast<HitOut*>(out);
+    const Scene& scene = *rs->scene;
+    const TriAccel* ta = scene.accel_->triangles_;
+    parallelFor(n, nthreads, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            Ray ray = makeRay(rays + i * 8);
+            RayHitInfo isect;
+            std::memset(&isect, 0, sizeof isect);
+            bool hit = scene.intersect(ray, &isect);
+            HitOut r;
+            std::memset(&r, 0, sizeof r);
+            r.hit = hit ? 1 : 0;
+            r.t = isect.t;
+            r.prim = -1;
+            if (hit) {
+                r.u = isect.u; r.v = isect.v;
+                r.normal[0] = isect.normal.x; r.normal[1] = isect.normal.y; r.normal[2] = isect.normal.z;
+                r.shadingNormal[0] = isect.shadingNormal.x;
+                r.shadingNormal[1] = isect.shadingNormal.y;
+                r.shadingNormal[2] = isect.shadingNormal.z;
+                if (isect.areaLight != nullptr) {
+                    size_t s = (reinterpret_cast<uintptr_t>(isect.areaLight) - 0x1000) / 16;
+                    r.prim = -(int32_t)s - 2;
+                    r.ambiguous = 1;
+                } else {
+                    int32_t mesh = rs->bsdfToMesh.at(isect.bsdf);
+                    for (int32_t slot : rs->meshLeafSlots[mesh]) {
+                        RayHitInfo probe;
+                        probe.t = std::numeric_limits<float>::infinity();
+                        if (::intersect(ta[slot], ray, &probe) &&
+                            std::memcmp(&probe.t, &isect.t, 4) == 0 &&
+                            std::memcmp(&probe.u, &isect.u, 4) == 0 &&
+                            std::memcmp(&probe.v, &isect.v, 4) == 0) {
+                            if (r.ambiguous == 0) r.prim = slot;
+                            r.ambiguous++;
+                        }
+                    }
+                }
+            }
+            o[i] = r;
+        }
+    });
+}
+
+// Scene::intersectShadow (include/scene.h:170)
+void ref_intersect_shadow(void* h, const float* rays, size_t n, uint8_t* out, int nthreads)
+{
+    const Scene& scene = *static_cast<RefScene*>(h)->scene;
+    parallelFor(n, nthreads, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            Ray ray = makeRay(rays + i * 8);
+            out[i] = scene.intersectShadow(ray) ? 1 : 0;
+        }
+    });
+}
+
+// Throughput loop for the CPU baseline: nothing but Scene::intersect per ray,
+// striding worker threads over the ray array the way the reference's tile
+// workers would (src/scheduler.cpp:46-72).  Writes t only.
+void ref_intersect_throughput(void* h, const float* rays, size_t n, float* tOut, int nthreads)
+{
+    const Scene& scene = *static_cast<RefScene*>(h)->scene;
+    parallelFor(n, nthreads, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            Ray ray = makeRay(rays + i * 8);
+            RayHitInfo isect;
+            scene.intersect(ray, &isect);
+            tOut[i] = isect.t;
+        }
+    });
+}
+
+// Geometry of Scene::makeCornellBox() (src/scene.cpp:4-157) flattened into the
+// exchange format.  Call with null pointers to get the counts.
+void ref_cornell(float* verts, size_t* nVerts, int32_t* tris, size_t* nTris,
+                 float* spheres, size_t* nSpheres)
+{
+    Scene s = Scene::makeCornellBox();
+    size_t nv = 0, nt = 0;
+    for (size_t m = 0; m < s.meshes_.size(); ++m) {
+        const auto& mesh = s.meshes_[m];
+        const auto& v = mesh.vertices_;
+        const auto& t = mesh.triangles_;
+        for (size_t k = 0; k < t.size(); ++k) {
+            if (tris) {
+                tris[(nt + k) * 5 + 0] = t[k].idx0 + (int32_t)nv;
+                tris[(nt + k) * 5 + 1] = t[k].idx1 + (int32_t)nv;
+                tris[(nt + k) * 5 + 2] = t[k].idx2 + (int32_t)nv;
+                tris[(nt + k) * 5 + 3] = (int32_t)m;
+                tris[(nt + k) * 5 + 4] = (int32_t)k;
+            }
+        }
+        for (size_t k = 0; k < v.size(); ++k) {
+            if (verts) {
+                verts[(nv + k) * 3 + 0] = v[k].x;
+                verts[(nv + k) * 3 + 1] = v[k].y;
+                verts[(nv + k) * 3 + 2] = v[k].z;
+            }
+        }
+        nv += v.size();
+        nt += t.size();
+    }
+    for (size_t i = 0; i < s.shapes_.size(); ++i) {
+        auto* sp = static_cast<Sphere*>(s.shapes_[i].get());
+        if (spheres) {
+            spheres[i * 4 + 0] = sp->position_.x;
+            spheres[i * 4 + 1] = sp->position_.y;
+            spheres[i * 4 + 2] = sp->position_.z;
+            spheres[i * 4 + 3] = sp->radius_;
+        }
+    }
+    *nVerts = nv; *nTris = nt; *nSpheres = s.shapes_.size();
+}
+
+// Camera::sample (include/camera.h:24-31) for an array of film positions.
+// Only the inline constructor and sample() are used; src/bitmap.cpp (which
+// does not compile on g++ 11) is neither built nor needed.
+void ref_camera_rays(const float* pos, const float* dir, int width, int height, float fov,
+                     const float* xy, size_t n, float* raysOut)
+{
+    Camera cam(Vector3f(pos[0], pos[1], pos[2]), normal(Vector3f(dir[0], dir[1], dir[2])),
+               width, height, fov);
+    for (size_t i = 0; i < n; ++i) {
+        Ray r = cam.sample(xy[i * 2 + 0], xy[i * 2 + 1]);
+        float* o = raysOut + i * 8;
+        o[0] = r.orig.x; o[1] = r.orig.y; o[2] = r.orig.z; o[3] = r.minT;
+        o[4] = r.dir.x;  o[5] = r.dir.y;  o[6] = r.dir.z;  o[7] = r.maxT;
+    }
+}
+
+// uniformSphereSample (include/qmc.h:82-94), used for the "incoherent" ray set
+void ref_uniform_sphere(const float* u12, size_t n, float* dirOut)
+{
+    for (size_t i = 0; i < n; ++i) {
+        Vector3f d = uniformSphereSample(u12[i * 2], u12[i * 2 + 1]);
+        dirOut[i * 3 + 0] = d.x; dirOut[i * 3 + 1] = d.y; dirOut[i * 3 + 2] = d.z;
+    }
+}
+
+} // extern "C"
