@@ -1,0 +1,181 @@
+/* yart_amd.h -- C-ABI of the MI355X ray-intersection engine for yart.
+ *
+ * This is the drop-in boundary for ONE path of elaic/yart: BVH traversal plus
+ * Wald-projected-triangle and sphere intersection, closest-hit and any-hit.
+ * Every entry point below names the reference interface it replaces
+ * (file:line relative to the reference tree).  Plain pointers and sizes only;
+ * no C++ or torch types.  All functions return a yart_status (0 = success);
+ * hit / miss is DATA in the output arrays, never the return value.
+ *
+ * Threading: an accel is immutable after creation; intersect calls may be
+ * issued concurrently from several host threads on distinct streams.
+ */
+#ifndef YART_AMD_H
+#define YART_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- records --------------------------------------------------------- */
+
+/* Ray, 32 bytes: the reference's `struct Ray` (include/vector.h:238-250).
+ * dir must be unit length (the reference's sphere test assumes it,
+ * include/sphere.h:67-68). */
+typedef struct YartRay {
+    float ox, oy, oz, tmin;
+    float dx, dy, dz, tmax;
+} YartRay;
+
+/* Hit, 16 bytes: the fields of the reference's RayHitInfo that the hot path
+ * produces (t, u, v; include/vector.h:255-263) plus the primitive identity the
+ * reference derives its normal / bsdf / areaLight from but never exposes
+ * (src/bvhaccel.cpp:283-292, include/sphere.h:79-83).
+ *   prim >= 0   triangle: index into the leaf-ordered TriAccel array
+ *               (yart_accel_get_triaccel; its triIdx/meshIdx give mesh ids)
+ *   prim == -1  miss; t == ray.tmax, u == v == 0
+ *   prim <= -2  sphere number -(prim + 2) of the `spheres` array; u == v == 0 */
+typedef struct YartHit {
+    float t, u, v;
+    int32_t prim;
+} YartHit;
+
+/* 48-byte Wald triangle record, the reference's `struct TriAccel`
+ * (include/triaccel.h:16-32), bit-for-bit. */
+typedef struct YartTriAccel {
+    float n_u, n_v, n_d; int32_t k;
+    float b_u, b_v, b_d; int32_t triIdx;
+    float c_u, c_v, c_d; int32_t meshIdx;
+} YartTriAccel;
+
+/* 32-byte flattened BVH node, the reference's FlattenedBvhNode
+ * (src/bvhaccel.cpp:64-93) in the reference's own depth-first order; the
+ * reference leaves numTriangles uninitialised in interior nodes, here it is 0. */
+typedef struct YartBvhNode {
+    float bounds_min[3];
+    float bounds_max[3];
+    uint32_t offset;        /* interior: childOffset (right child); leaf: triangleOffset */
+    uint8_t num_triangles;
+    uint8_t split_axis;     /* 0,1,2 = interior split axis; 3 = leaf */
+    uint8_t pad[2];
+} YartBvhNode;
+
+typedef struct YartAccel YartAccel;
+
+enum yart_status {
+    YART_OK = 0,
+    YART_ERR_INVALID_ARGUMENT = 1,
+    YART_ERR_NO_DEVICE = 2,       /* no HIP device / HIP runtime failure at create */
+    YART_ERR_HIP = 3,             /* a HIP call failed; see yart_last_error() */
+    YART_ERR_OUT_OF_MEMORY = 4,
+    YART_ERR_TREE_TOO_DEEP = 5    /* BVH deeper than the 64-entry traversal stack the
+                                     reference also assumes (src/bvhaccel.cpp:242-244) */
+};
+
+/* flags for the intersect calls */
+enum yart_flags {
+    YART_DEFAULT        = 0,
+    /* Traverse with the reference's exact rule: box interval [minT,maxT], no
+     * distance pruning (include/bbox.h:30-50), every sphere considered.  Results
+     * are bit-identical to the reference for every ray.  Slow; for parity runs. */
+    YART_REFERENCE_RULE = 1u << 0,
+    /* Launch one lane per ray over a plain grid instead of the persistent
+     * work-pulling kernel (A/B measurements). */
+    YART_STATIC_LAUNCH  = 1u << 1,
+    /* Sort the batch by a Morton key of origin + direction octant before
+     * traversal (results are written back in the caller's order). */
+    YART_SORT_RAYS      = 1u << 2
+};
+
+/* ---- accel lifetime -------------------------------------------------- */
+
+/* Replaces Scene::preprocess() -> BvhAccel::BvhAccel(const Scene&)
+ * (include/scene.h:37-74, src/bvhaccel.cpp:309-363) and the ownership of
+ * Scene::shapes_ for the sphere loop (include/scene.h:142-144).
+ *
+ *   verts    n_verts x 3 floats
+ *   tris     n_tris x 5 int32: v0, v1, v2 (indices into verts), meshId, triId,
+ *            listed in the order the reference enumerates them: mesh by mesh,
+ *            triangle by triangle (src/bvhaccel.cpp:328-343) -- the builder's
+ *            partition order, and so the leaf order, depends on it
+ *   spheres  n_spheres x 4 floats: cx, cy, cz, radius, in Scene::shapes_ order
+ *   device   HIP device ordinal the accel lives on
+ *
+ * The host builds the reference's tree (same topology, same leaf order, same
+ * TriAccel bits) and uploads it once; nothing is read from the input arrays
+ * after the call returns. */
+int yart_accel_create(const float* verts, size_t n_verts,
+                      const int32_t* tris, size_t n_tris,
+                      const float* spheres, size_t n_spheres,
+                      int device, YartAccel** out);
+
+/* Replaces BvhAccel::~BvhAccel (src/bvhaccel.cpp:365-368). */
+void yart_accel_destroy(YartAccel* accel);
+
+/* ---- intersection: rays and results already resident in HBM ----------- */
+
+/* Replaces Scene::intersect(const Ray&, RayHitInfo*) (include/scene.h:136-168)
+ * -> Shape::intersect loop + BvhAccel::intersect (src/bvhaccel.cpp:370-373),
+ * for a batch of n rays.  d_rays / d_hits are device pointers on the accel's
+ * device; `stream` is a hipStream_t (NULL = default stream).  Asynchronous. */
+int yart_intersect_closest_dev(YartAccel* accel, const YartRay* d_rays, size_t n,
+                               YartHit* d_hits, unsigned flags, void* stream);
+
+/* Replaces Scene::intersectShadow(const Ray&) (include/scene.h:170-194) ->
+ * BvhAccel::intersectShadow (src/bvhaccel.cpp:375-381).  d_occluded[i] = 1 if
+ * any primitive is accepted in (1e-4, ray.tmax), else 0. */
+int yart_intersect_any_dev(YartAccel* accel, const YartRay* d_rays, size_t n,
+                           uint8_t* d_occluded, unsigned flags, void* stream);
+
+/* As above and additionally writes, per ray, three uint32 fetch counters:
+ * 32-byte node records fetched, 48-byte triangle records tested, 16-byte
+ * sphere records tested -- the terms of the algorithmic bytes per ray
+ * (SURVEY.md 8d).  Diagnostic; slower. */
+int yart_intersect_closest_counted_dev(YartAccel* accel, const YartRay* d_rays, size_t n,
+                                       YartHit* d_hits, uint32_t* d_counts,
+                                       unsigned flags, void* stream);
+int yart_intersect_any_counted_dev(YartAccel* accel, const YartRay* d_rays, size_t n,
+                                   uint8_t* d_occluded, uint32_t* d_counts,
+                                   unsigned flags, void* stream);
+
+/* ---- intersection: host buffers (copies in, runs, copies out, syncs) --- */
+
+/* Same contracts as the _dev calls; the batch-of-one form of these is what the
+ * C++ shim (yart_amd/cxx/yart_shim.hpp) forwards Scene::intersect /
+ * Scene::intersectShadow to. */
+int yart_intersect_closest(YartAccel* accel, const YartRay* rays, size_t n,
+                           YartHit* hits, unsigned flags);
+int yart_intersect_any(YartAccel* accel, const YartRay* rays, size_t n,
+                       uint8_t* occluded, unsigned flags);
+
+/* ---- introspection (parity dumps) ------------------------------------- */
+
+/* The reference's private BvhAccel::optimizedAccel_ / triangles_
+ * (include/bvhaccel.h:57-58) as built by this library. */
+size_t yart_accel_num_nodes(const YartAccel* accel);
+size_t yart_accel_num_triangles(const YartAccel* accel);
+size_t yart_accel_num_spheres(const YartAccel* accel);
+int yart_accel_get_nodes(const YartAccel* accel, YartBvhNode* out);
+int yart_accel_get_triaccel(const YartAccel* accel, YartTriAccel* out);
+/* Depth of the triangle tree (root = 1) and bytes resident in HBM. */
+int yart_accel_depth(const YartAccel* accel);
+size_t yart_accel_device_bytes(const YartAccel* accel);
+
+/* Host-only build (no HIP call): fills the same arrays the accel would hold.
+ * Pass NULL outputs to query the counts.  Used by CPU-side tests. */
+int yart_build_host(const float* verts, size_t n_verts,
+                    const int32_t* tris, size_t n_tris,
+                    YartBvhNode* nodes_out, size_t* n_nodes,
+                    YartTriAccel* triaccel_out);
+
+const char* yart_status_string(int status);
+/* Text of the last failure on the calling thread ("" if none). */
+const char* yart_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YART_AMD_H */

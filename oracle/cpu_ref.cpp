@@ -385,8 +385,8 @@ bool traverseEngine(const Scene& sc, const Ray& r, Hit& h, Counters* c)
     uint32_t stack[64];
     int sp = 0;
     bool hit = false;
-    // root is tested on its own (one 32-byte record)
-    if (c) c->nodes++;
+    // the root sits in pair 0 next to an empty leaf: one 64-byte fetch = 2 records
+    if (c) c->nodes += 2;
     if (!slab(sc.nodes[0].b, r, shadow ? r.tmax : h.t)) return false;
     uint32_t cur = 0;
     for (;;) {

@@ -1,0 +1,171 @@
+"""GPU: the HIP path, called through the C-ABI, against the golden vectors of the real
+reference and against the oracle on seeded inputs.
+
+Bars (BASELINE.json north_star / SURVEY.md 8d):
+  * YART_REFERENCE_RULE  -> bit-exact: same primitive for every ray, identical t/u/v bits
+  * default (pruned)     -> hit/miss identical, same primitive for >= 99.99 % of rays,
+                            |t - t_ref| <= 1e-5 |t_ref|
+  * any-hit              -> identical booleans
+"""
+import numpy as np
+import pytest
+
+from conftest import bits
+from yart_amd import api, scenes
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+REL_T = 1e-5
+MIN_SAME_PRIM = 0.9999
+
+LAUNCHES = [0, api.YART_STATIC_LAUNCH, api.YART_SORT_RAYS, api.YART_SORT_RAYS | api.YART_STATIC_LAUNCH]
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def assert_exact(got, want_prim, want_t, want_u, want_v):
+    hit = want_prim != -1
+    assert np.array_equal(got["prim"], want_prim)
+    assert np.array_equal(bits(got["t"]), bits(want_t))
+    assert np.array_equal(bits(got["u"][hit]), bits(want_u[hit]))
+    assert np.array_equal(bits(got["v"][hit]), bits(want_v[hit]))
+
+
+def assert_within_bar(got, want_prim, want_t):
+    assert np.array_equal(got["prim"] != -1, want_prim != -1), "hit/miss differs"
+    same = (got["prim"] == want_prim).mean()
+    assert same >= MIN_SAME_PRIM, same
+    m = want_prim != -1
+    rel = np.abs(got["t"][m] - want_t[m]) / np.abs(want_t[m])
+    assert rel.size == 0 or rel.max() <= REL_T, rel.max()
+
+
+@pytest.fixture(scope="module")
+def accel(golden):
+    a = api.Accel(golden["verts"], golden["tris"], golden["spheres"], device=0)
+    yield a
+    a.close()
+
+
+def test_accel_arrays_match_reference(golden, accel):
+    assert accel.nodes().tobytes() == golden["nodes"].tobytes()
+    assert accel.triaccel().tobytes() == golden["triaccel"].tobytes()
+    assert accel.num_spheres == len(golden["spheres"])
+
+
+@pytest.mark.parametrize("launch", LAUNCHES)
+def test_closest_reference_rule_is_bit_exact(golden, accel, launch):
+    got = api.hits_to_numpy(accel.intersect_closest(dev(golden["rays"]), api.YART_REFERENCE_RULE | launch))
+    assert_exact(got, golden["prim"], golden["t"], golden["u"], golden["v"])
+
+
+@pytest.mark.parametrize("launch", LAUNCHES)
+def test_closest_pruned_within_bar(golden, accel, launch):
+    got = api.hits_to_numpy(accel.intersect_closest(dev(golden["rays"]), launch))
+    assert_within_bar(got, golden["prim"], golden["t"])
+
+
+@pytest.mark.parametrize("launch", LAUNCHES)
+@pytest.mark.parametrize("rule", [0, api.YART_REFERENCE_RULE])
+def test_any_hit_matches_reference(golden, accel, launch, rule):
+    occ = accel.intersect_any(dev(golden["shadow_rays"]), rule | launch).cpu().numpy()
+    assert np.array_equal(occ, golden["occluded"])
+
+
+def test_host_buffer_entry_points(golden, accel):
+    got = accel.intersect_closest_host(golden["rays"], api.YART_REFERENCE_RULE)
+    assert_exact(got, golden["prim"], golden["t"], golden["u"], golden["v"])
+    occ = accel.intersect_any_host(golden["shadow_rays"])
+    assert np.array_equal(occ, golden["occluded"])
+
+
+def test_fetch_counters_match_cpu_counting_oracle(golden, accel):
+    """The counting kernel and the oracle's restatement of the engine rule must agree on
+    the per-ray node / triangle fetch counts that define the algorithmic bytes."""
+    from oracle import oracle as orc
+    o = orc.Oracle(golden["verts"], golden["tris"], golden["spheres"])
+    _, want = o.intersect(golden["rays"], mode=1, counts=True)
+    rays = dev(golden["rays"])
+    counts = torch.zeros((len(golden["rays"]), 3), dtype=torch.int32, device="cuda")
+    hits = api.hits_to_numpy(accel.intersect_closest(rays, 0, counts=counts))
+    got = counts.cpu().numpy().astype(np.uint32)
+    assert_within_bar(hits, golden["prim"], golden["t"])
+    if len(golden["spheres"]) == 0:
+        assert np.array_equal(got[:, 0], want[:, 0])
+    assert np.array_equal(got[:, 1], want[:, 1])           # triangle records tested
+    assert (got[:, 2] <= want[:, 2]).all()                 # sphere BVH never tests more than the linear loop
+    _, want_any = o.intersect_shadow(golden["shadow_rays"], mode=1, counts=True)
+    counts.zero_()
+    accel.intersect_any(dev(golden["shadow_rays"]), 0, counts=counts)
+    got_any = counts.cpu().numpy().astype(np.uint32)
+    assert np.array_equal(got_any[:, 1], want_any[:, 1])
+
+
+def test_empty_and_tiny_batches(accel, golden):
+    assert accel.intersect_closest(torch.empty((0, 8), dtype=torch.float32, device="cuda")).shape == (0, 4)
+    one = api.hits_to_numpy(accel.intersect_closest(dev(golden["rays"][:1])))
+    assert one["prim"][0] == golden["prim"][0]
+    for n in (1, 63, 64, 65, 255, 257):
+        got = api.hits_to_numpy(accel.intersect_closest(dev(golden["rays"][:n]), api.YART_REFERENCE_RULE))
+        assert np.array_equal(got["prim"], golden["prim"][:n])
+
+
+def test_empty_scene():
+    a = api.Accel(np.zeros((0, 3), np.float32), np.zeros((0, 5), np.int32), None)
+    rays = scenes.random_rays(1000)
+    got = api.hits_to_numpy(a.intersect_closest(dev(rays)))
+    assert (got["prim"] == -1).all() and np.isinf(got["t"]).all()
+    assert a.intersect_any(dev(rays)).sum().item() == 0
+    a.close()
+
+
+def test_spheres_only_scene_matches_oracle():
+    from oracle import oracle as orc
+    _, _, sph = scenes.random_soup(0, 3000, s=0.05, seed=12)
+    v = np.zeros((0, 3), np.float32)
+    t = np.zeros((0, 5), np.int32)
+    rays = scenes.random_rays(20000, seed=13)
+    a = api.Accel(v, t, sph)
+    want = orc.Oracle(v, t, sph).intersect(rays)
+    exact = api.hits_to_numpy(a.intersect_closest(dev(rays), api.YART_REFERENCE_RULE))
+    assert_exact(exact, want["prim"], want["t"], want["u"], want["v"])
+    fast = api.hits_to_numpy(a.intersect_closest(dev(rays), api.YART_SORT_RAYS))
+    assert_within_bar(fast, want["prim"], want["t"])
+    a.close()
+
+
+@pytest.mark.parametrize("n_tris,n_sph,s,n_rays", [(200000, 256, 0.01, 1 << 18), (50000, 0, 0.002, 1 << 17)])
+def test_seeded_soup_against_oracle(n_tris, n_sph, s, n_rays):
+    """C4-shaped inputs at a size the oracle finishes in seconds."""
+    from oracle import oracle as orc
+    v, t, sph = scenes.random_soup(n_tris, n_sph, s=s, seed=42)
+    rays = scenes.random_rays(n_rays, seed=7)
+    shadow = scenes.random_rays(n_rays, seed=8, tmax=0.5)
+    a = api.Accel(v, t, sph)
+    o = orc.Oracle(v, t, sph)
+    want = o.intersect(rays, mode=0, nthreads=16)
+    want_occ = o.intersect_shadow(shadow, mode=0, nthreads=16)
+    exact = api.hits_to_numpy(a.intersect_closest(dev(rays), api.YART_REFERENCE_RULE))
+    assert_exact(exact, want["prim"], want["t"], want["u"], want["v"])
+    for launch in (0, api.YART_SORT_RAYS):
+        fast = api.hits_to_numpy(a.intersect_closest(dev(rays), launch))
+        assert_within_bar(fast, want["prim"], want["t"])
+        assert np.array_equal(a.intersect_any(dev(shadow), launch).cpu().numpy(), want_occ)
+    a.close()
+
+
+def test_architectural_primary_rays_against_oracle():
+    """C2-shaped input (coherent pinhole camera rays into the Sponza-class stand-in)."""
+    from oracle import oracle as orc
+    v, t, sph = scenes.architectural(60000, seed=1)
+    rays = scenes.camera_rays([-10.0, 5.0, 0.0], [1.0, -0.1, 0.05], 320, 180, 0.785398)
+    a = api.Accel(v, t, sph)
+    want = orc.Oracle(v, t, sph).intersect(rays, mode=0, nthreads=16)
+    exact = api.hits_to_numpy(a.intersect_closest(dev(rays), api.YART_REFERENCE_RULE))
+    assert_exact(exact, want["prim"], want["t"], want["u"], want["v"])
+    fast = api.hits_to_numpy(a.intersect_closest(dev(rays)))
+    assert_within_bar(fast, want["prim"], want["t"])
+    a.close()

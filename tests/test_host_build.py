@@ -1,0 +1,81 @@
+"""CPU: the product's host-side builder (yart_amd/csrc/bvh_build.cpp, reached through the
+C-ABI's yart_build_host) must produce the reference's node and TriAccel arrays bit for
+bit, and the C-ABI library must load and export every symbol include/yart_amd.h declares.
+No compute entry point is called here (there is no GPU in the CPU suite)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from yart_amd import api, scenes
+
+
+def test_library_exports_every_declared_symbol():
+    L = api.lib()
+    header = open(os.path.join(ROOT, "include", "yart_amd.h")).read()
+    declared = set(re.findall(r"^(?:int|void|size_t|const char\*)\s+(yart_[a-z_]+)\s*\(", header, re.M))
+    assert declared, "no declarations found"
+    assert declared == set(api.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_record_sizes():
+    assert api.NODE_DTYPE.itemsize == 32
+    assert api.TRIACCEL_DTYPE.itemsize == 48
+    assert api.HIT_DTYPE.itemsize == 16
+
+
+def test_builder_matches_reference_golden(golden):
+    nodes, ta = api.build_host(golden["verts"], golden["tris"])
+    assert nodes.tobytes() == golden["nodes"].tobytes()
+    assert ta.tobytes() == golden["triaccel"].tobytes()
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 9, 63, 64, 1000])
+def test_builder_matches_oracle_on_ragged_sizes(n):
+    from oracle import oracle as orc
+    v, t, s = scenes.random_soup(n, 0, s=0.1, seed=n + 1, tris_per_mesh=5)
+    nodes, ta = api.build_host(v, t)
+    o = orc.Oracle(v, t, s)
+    assert nodes.tobytes() == o.nodes().tobytes()
+    assert ta.tobytes() == o.triaccel().tobytes()
+
+
+def test_builder_median_fallback_and_ties():
+    """All centres equal on the split axis -> std::partition leaves one side empty ->
+    the std::nth_element median path (src/bvhaccel.cpp:134-143)."""
+    from oracle import oracle as orc
+    n = 40
+    v = np.zeros((n * 3, 3), np.float32)
+    for i in range(n):
+        v[i * 3:(i + 1) * 3] = [[0, 0, 0], [1, 0, 0], [0, 1, 0]]       # 40 identical triangles
+    t = np.zeros((n, 5), np.int32)
+    t[:, 0] = np.arange(n) * 3
+    t[:, 1] = t[:, 0] + 1
+    t[:, 2] = t[:, 0] + 2
+    t[:, 3] = np.arange(n)
+    nodes, ta = api.build_host(v, t)
+    o = orc.Oracle(v, t, np.zeros((0, 4), np.float32))
+    assert nodes.tobytes() == o.nodes().tobytes()
+    assert ta.tobytes() == o.triaccel().tobytes()
+
+
+def test_bad_vertex_index_is_rejected():
+    v = np.zeros((3, 3), np.float32)
+    t = np.array([[0, 1, 5, 0, 0]], np.int32)
+    with pytest.raises(api.YartError):
+        api.build_host(v, t)
+
+
+def test_no_gpu_means_loud_failure():
+    """Without a HIP device the product must fail, not fall back to a CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    v, t, s = scenes.random_soup(16)
+    with pytest.raises(api.YartError):
+        api.Accel(v, t, s)

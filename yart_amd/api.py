@@ -1,0 +1,231 @@
+"""ctypes binding of the C-ABI in include/yart_amd.h (libyart_amd.so).
+
+PyTorch is used only as plumbing: device buffers and streams.  There is no CPU
+fallback of any kind here -- if the HIP library is missing, or no GPU is present,
+the calls raise.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyart_amd.so")
+
+YART_DEFAULT = 0
+YART_REFERENCE_RULE = 1 << 0
+YART_STATIC_LAUNCH = 1 << 1
+YART_SORT_RAYS = 1 << 2
+
+NODE_DTYPE = np.dtype([("bounds", np.float32, 6), ("offset", np.uint32),
+                       ("numTriangles", np.uint8), ("splitAxis", np.uint8),
+                       ("pad", np.uint8, 2)])
+TRIACCEL_DTYPE = np.dtype([("n_u", np.float32), ("n_v", np.float32), ("n_d", np.float32), ("k", np.int32),
+                           ("b_u", np.float32), ("b_v", np.float32), ("b_d", np.float32), ("triIdx", np.int32),
+                           ("c_u", np.float32), ("c_v", np.float32), ("c_d", np.float32), ("meshIdx", np.int32)])
+HIT_DTYPE = np.dtype([("t", np.float32), ("u", np.float32), ("v", np.float32), ("prim", np.int32)])
+
+EXPORTS = [
+    "yart_accel_create", "yart_accel_destroy",
+    "yart_intersect_closest_dev", "yart_intersect_any_dev",
+    "yart_intersect_closest_counted_dev", "yart_intersect_any_counted_dev",
+    "yart_intersect_closest", "yart_intersect_any",
+    "yart_accel_num_nodes", "yart_accel_num_triangles", "yart_accel_num_spheres",
+    "yart_accel_get_nodes", "yart_accel_get_triaccel", "yart_accel_depth",
+    "yart_accel_device_bytes", "yart_build_host", "yart_status_string", "yart_last_error",
+]
+
+_vp = ctypes.c_void_p
+_sz = ctypes.c_size_t
+_lib = None
+
+
+class YartError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libyart_amd.so; raises if it was not built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise YartError("%s not found: build it with `make -C yart_amd/csrc` "
+                        "(or __graft_entry__.build()); there is no fallback path" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    L.yart_accel_create.argtypes = [_vp, _sz, _vp, _sz, _vp, _sz, ctypes.c_int, ctypes.POINTER(_vp)]
+    L.yart_accel_destroy.argtypes = [_vp]
+    L.yart_accel_destroy.restype = None
+    for name in ("yart_intersect_closest_dev", "yart_intersect_any_dev"):
+        getattr(L, name).argtypes = [_vp, _vp, _sz, _vp, ctypes.c_uint, _vp]
+    for name in ("yart_intersect_closest_counted_dev", "yart_intersect_any_counted_dev"):
+        getattr(L, name).argtypes = [_vp, _vp, _sz, _vp, _vp, ctypes.c_uint, _vp]
+    for name in ("yart_intersect_closest", "yart_intersect_any"):
+        getattr(L, name).argtypes = [_vp, _vp, _sz, _vp, ctypes.c_uint]
+    for name in ("yart_accel_num_nodes", "yart_accel_num_triangles", "yart_accel_num_spheres",
+                 "yart_accel_device_bytes"):
+        getattr(L, name).argtypes = [_vp]
+        getattr(L, name).restype = _sz
+    L.yart_accel_depth.argtypes = [_vp]
+    L.yart_accel_get_nodes.argtypes = [_vp, _vp]
+    L.yart_accel_get_triaccel.argtypes = [_vp, _vp]
+    L.yart_build_host.argtypes = [_vp, _sz, _vp, _sz, _vp, ctypes.POINTER(_sz), _vp]
+    L.yart_status_string.argtypes = [ctypes.c_int]
+    L.yart_status_string.restype = ctypes.c_char_p
+    L.yart_last_error.restype = ctypes.c_char_p
+    _lib = L
+    return L
+
+
+def _check(status):
+    if status != 0:
+        L = lib()
+        raise YartError("%s: %s" % (L.yart_status_string(status).decode(), L.yart_last_error().decode()))
+
+
+def _p(a):
+    return a.ctypes.data_as(_vp) if a is not None and a.size else None
+
+
+def _scene_arrays(verts, tris, spheres):
+    verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
+    tris = np.ascontiguousarray(tris, np.int32).reshape(-1, 5)
+    if spheres is None:
+        spheres = np.zeros((0, 4), np.float32)
+    spheres = np.ascontiguousarray(spheres, np.float32).reshape(-1, 4)
+    return verts, tris, spheres
+
+
+def build_host(verts, tris):
+    """Host-only build (no GPU needed): the reference-layout node and TriAccel arrays."""
+    L = lib()
+    verts, tris, _ = _scene_arrays(verts, tris, None)
+    n = _sz(0)
+    _check(L.yart_build_host(_p(verts), len(verts), _p(tris), len(tris), None, ctypes.byref(n), None))
+    nodes = np.zeros(n.value, NODE_DTYPE)
+    ta = np.zeros(len(tris), TRIACCEL_DTYPE)
+    _check(L.yart_build_host(_p(verts), len(verts), _p(tris), len(tris), _p(nodes), ctypes.byref(n), _p(ta)))
+    return nodes, ta
+
+
+class Accel:
+    """A scene resident in one GPU's HBM (yart_accel_create)."""
+
+    def __init__(self, verts, tris, spheres=None, device=0):
+        self._h = None
+        L = lib()
+        verts, tris, spheres = _scene_arrays(verts, tris, spheres)
+        h = _vp()
+        _check(L.yart_accel_create(_p(verts), len(verts), _p(tris), len(tris), _p(spheres), len(spheres),
+                                   int(device), ctypes.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if self._h:
+            lib().yart_accel_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- introspection ------------------------------------------------------
+    @property
+    def num_nodes(self):
+        return lib().yart_accel_num_nodes(self._h)
+
+    @property
+    def num_triangles(self):
+        return lib().yart_accel_num_triangles(self._h)
+
+    @property
+    def num_spheres(self):
+        return lib().yart_accel_num_spheres(self._h)
+
+    @property
+    def depth(self):
+        return lib().yart_accel_depth(self._h)
+
+    @property
+    def device_bytes(self):
+        return lib().yart_accel_device_bytes(self._h)
+
+    def nodes(self):
+        out = np.zeros(self.num_nodes, NODE_DTYPE)
+        if out.size:
+            _check(lib().yart_accel_get_nodes(self._h, _p(out)))
+        return out
+
+    def triaccel(self):
+        out = np.zeros(self.num_triangles, TRIACCEL_DTYPE)
+        if out.size:
+            _check(lib().yart_accel_get_triaccel(self._h, _p(out)))
+        return out
+
+    # -- device-resident batches (torch tensors on this accel's GPU) --------
+    def _stream(self, stream):
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        return _vp(stream.cuda_stream)
+
+    def _rays(self, rays):
+        import torch
+        if not (isinstance(rays, torch.Tensor) and rays.is_cuda and rays.dtype == torch.float32
+                and rays.is_contiguous() and rays.dim() == 2 and rays.shape[1] == 8):
+            raise YartError("rays must be a contiguous float32 CUDA tensor of shape [n, 8]")
+        if rays.device.index != self.device:
+            raise YartError("rays live on another device than the accel")
+        return rays
+
+    def intersect_closest(self, rays, flags=0, out=None, counts=None, stream=None):
+        """rays [n,8] float32 -> hits [n,4] float32 (t,u,v,prim-as-int32-bits)."""
+        import torch
+        rays = self._rays(rays)
+        n = rays.shape[0]
+        if out is None:
+            out = torch.empty((n, 4), dtype=torch.float32, device=rays.device)
+        if counts is not None:
+            _check(lib().yart_intersect_closest_counted_dev(self._h, _vp(rays.data_ptr()), n, _vp(out.data_ptr()),
+                                                            _vp(counts.data_ptr()), flags, self._stream(stream)))
+        else:
+            _check(lib().yart_intersect_closest_dev(self._h, _vp(rays.data_ptr()), n, _vp(out.data_ptr()),
+                                                    flags, self._stream(stream)))
+        return out
+
+    def intersect_any(self, rays, flags=0, out=None, counts=None, stream=None):
+        """rays [n,8] float32 -> occluded [n] uint8."""
+        import torch
+        rays = self._rays(rays)
+        n = rays.shape[0]
+        if out is None:
+            out = torch.empty((n,), dtype=torch.uint8, device=rays.device)
+        if counts is not None:
+            _check(lib().yart_intersect_any_counted_dev(self._h, _vp(rays.data_ptr()), n, _vp(out.data_ptr()),
+                                                        _vp(counts.data_ptr()), flags, self._stream(stream)))
+        else:
+            _check(lib().yart_intersect_any_dev(self._h, _vp(rays.data_ptr()), n, _vp(out.data_ptr()),
+                                                flags, self._stream(stream)))
+        return out
+
+    # -- host buffers (numpy) -----------------------------------------------
+    def intersect_closest_host(self, rays, flags=0):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        hits = np.zeros(len(rays), HIT_DTYPE)
+        _check(lib().yart_intersect_closest(self._h, _p(rays), len(rays), _p(hits), flags))
+        return hits
+
+    def intersect_any_host(self, rays, flags=0):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        occ = np.zeros(len(rays), np.uint8)
+        _check(lib().yart_intersect_any(self._h, _p(rays), len(rays), _p(occ), flags))
+        return occ
+
+
+def hits_to_numpy(hits_tensor):
+    """[n,4] float32 device tensor -> structured numpy array (t,u,v,prim)."""
+    a = hits_tensor.detach().cpu().numpy()
+    return np.ascontiguousarray(a).view(HIT_DTYPE).reshape(-1)

@@ -1,0 +1,348 @@
+// capi.cpp -- the C-ABI of include/yart_amd.h: accel lifetime, launches, host-buffer
+// convenience calls.  All device work is in traverse.hip / sort.hip; there is no CPU
+// intersection path in this library -- without a HIP device every intersect call fails.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+
+#include "../../include/yart_amd.h"
+#include "bvh_build.h"
+#include "traverse.h"
+
+namespace {
+
+thread_local std::string g_lastError;
+
+int fail(int status, const std::string& msg)
+{
+    g_lastError = msg;
+    return status;
+}
+
+int failHip(hipError_t e, const char* what)
+{
+    g_lastError = std::string(what) + ": " + hipGetErrorString(e);
+    return YART_ERR_HIP;
+}
+
+constexpr int kCounterSlots = 64;     // 256-byte work-counter slots, handed out round-robin
+
+} // namespace
+
+struct YartAccel {
+    int device = 0;
+    int numCUs = 0;
+    yart::TriangleBvh tri;            // host copies (nodes / triaccel kept for introspection)
+    size_t numTriPairs = 0, numSphPairs = 0, numSpheres = 0;
+    int sphDepth = 0;
+    float sceneLo[3], sceneHi[3];     // bounds of everything, for the sort key grid
+    // device memory
+    void* dTriPairs = nullptr;
+    void* dTriAccel = nullptr;
+    void* dSphPairs = nullptr;
+    void* dSphRecs = nullptr;
+    void* dSphIndex = nullptr;
+    void* dCounters = nullptr;
+    size_t deviceBytes = 0;
+    std::atomic<unsigned> nextCounter{ 0 };
+
+    uint32_t* counterSlot()
+    {
+        const unsigned s = nextCounter.fetch_add(1) % kCounterSlots;
+        return reinterpret_cast<uint32_t*>(static_cast<char*>(dCounters) + 256 * s);
+    }
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+int upload(void** dst, const void* src, size_t bytes, size_t& total)
+{
+    *dst = nullptr;
+    if (bytes == 0) return YART_OK;
+    hipError_t e = hipMalloc(dst, bytes);
+    if (e != hipSuccess) return fail(YART_ERR_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e));
+    e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return failHip(e, "hipMemcpy H2D");
+    total += bytes;
+    return YART_OK;
+}
+
+struct Launch {
+    bool any, count;
+    const YartRay* rays;
+    size_t n;
+    YartHit* hits;
+    uint8_t* occluded;
+    uint32_t* counts;
+    unsigned flags;
+    hipStream_t stream;
+};
+
+int run(YartAccel* a, const Launch& L)
+{
+    if (!a) return fail(YART_ERR_INVALID_ARGUMENT, "null accel");
+    if (L.n == 0) return YART_OK;
+    if (!L.rays || (!L.any && !L.hits) || (L.any && !L.occluded) || (L.count && !L.counts))
+        return fail(YART_ERR_INVALID_ARGUMENT, "null ray / result pointer");
+    if (L.n > 0x7FFFFFFFu) return fail(YART_ERR_INVALID_ARGUMENT, "batch larger than 2^31-1 rays");
+    if ((reinterpret_cast<uintptr_t>(L.rays) & 15u) || (!L.any && (reinterpret_cast<uintptr_t>(L.hits) & 15u)))
+        return fail(YART_ERR_INVALID_ARGUMENT, "ray / hit arrays must be 16-byte aligned");
+    DeviceGuard guard(a->device);
+    if (!guard.ok) return fail(YART_ERR_NO_DEVICE, "hipSetDevice failed");
+
+    const bool prune = !(L.flags & YART_REFERENCE_RULE);
+    const bool persistent = !(L.flags & YART_STATIC_LAUNCH);
+    const uint32_t n = static_cast<uint32_t>(L.n);
+
+    uint32_t* perm = nullptr;
+    void* sortWs = nullptr;
+    if (L.flags & YART_SORT_RAYS) {
+        const size_t wsBytes = yart::sortWorkspaceBytes(n);
+        const size_t permBytes = (static_cast<size_t>(n) * 4 + 255) & ~size_t(255);
+        hipError_t e = hipMallocAsync(&sortWs, wsBytes + permBytes, L.stream);
+        if (e != hipSuccess) return fail(YART_ERR_OUT_OF_MEMORY, std::string("hipMallocAsync: ") + hipGetErrorString(e));
+        perm = reinterpret_cast<uint32_t*>(static_cast<char*>(sortWs) + wsBytes);
+        e = yart::sortRays(reinterpret_cast<const float4*>(L.rays), n, a->sceneLo, a->sceneHi, perm,
+                           sortWs, wsBytes, L.stream);
+        if (e != hipSuccess) { (void)hipFreeAsync(sortWs, L.stream); return failHip(e, "sortRays"); }
+    }
+
+    yart::TraceParams P;
+    std::memset(&P, 0, sizeof P);
+    P.rays = reinterpret_cast<const float4*>(L.rays);
+    P.perm = perm;
+    P.n = n;
+    P.hits = reinterpret_cast<float4*>(L.hits);
+    P.occluded = L.occluded;
+    P.counts = L.counts;
+    hipError_t e = hipSuccess;
+    if (a->numSpheres > 0) {
+        // Scene::intersect / intersectShadow visit the spheres before the triangle tree
+        // (include/scene.h:142-146, :176-182)
+        P.pairs = static_cast<const float4*>(a->dSphPairs);
+        P.prims = static_cast<const float4*>(a->dSphRecs);
+        P.primIndex = static_cast<const uint32_t*>(a->dSphIndex);
+        P.workCounter = a->counterSlot();
+        P.chained = 0;
+        e = yart::launchTrace(P, 1, L.any, prune, L.count, persistent, a->numCUs, L.stream);
+    }
+    if (e == hipSuccess) {
+        P.pairs = static_cast<const float4*>(a->dTriPairs);
+        P.prims = static_cast<const float4*>(a->dTriAccel);
+        P.primIndex = nullptr;
+        P.workCounter = a->counterSlot();
+        P.chained = a->numSpheres > 0 ? 1u : 0u;
+        e = yart::launchTrace(P, 0, L.any, prune, L.count, persistent, a->numCUs, L.stream);
+    }
+    if (sortWs) (void)hipFreeAsync(sortWs, L.stream);
+    if (e != hipSuccess) return failHip(e, "traversal launch");
+    return YART_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, size_t n_tris,
+                      const float* spheres, size_t n_spheres, int device, YartAccel** out)
+{
+    if (!out) return fail(YART_ERR_INVALID_ARGUMENT, "out is null");
+    *out = nullptr;
+    int nDev = 0;
+    if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0)
+        return fail(YART_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= nDev) return fail(YART_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+
+    YartAccel* a = new (std::nothrow) YartAccel();
+    if (!a) return fail(YART_ERR_OUT_OF_MEMORY, "host allocation failed");
+    a->device = device;
+    std::string err;
+    int st = yart::buildTriangleBvh(verts, n_verts, tris, n_tris, a->tri, err);
+    yart::SphereBvh sph;
+    if (st == YART_OK) st = yart::buildSphereBvh(spheres, n_spheres, sph, err);
+    if (st != YART_OK) { delete a; return fail(st, err); }
+    a->numTriPairs = a->tri.pairs.size();
+    a->numSphPairs = sph.pairs.size();
+    a->numSpheres = n_spheres;
+    a->sphDepth = sph.depth;
+
+    const float inf = std::numeric_limits<float>::infinity();
+    for (int c = 0; c < 3; ++c) { a->sceneLo[c] = inf; a->sceneHi[c] = -inf; }
+    auto growBy = [&](const yart::DevNodeRec& r) {
+        for (int c = 0; c < 3; ++c) {
+            if (r.lo[c] < a->sceneLo[c]) a->sceneLo[c] = r.lo[c];
+            if (r.hi[c] > a->sceneHi[c]) a->sceneHi[c] = r.hi[c];
+        }
+    };
+    if (n_tris) growBy(a->tri.pairs[0].child[0]);
+    if (n_spheres) growBy(sph.pairs[0].child[0]);
+
+    DeviceGuard guard(device);
+    if (!guard.ok) { delete a; return fail(YART_ERR_NO_DEVICE, "hipSetDevice failed"); }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete a; return fail(YART_ERR_NO_DEVICE, "hipGetDeviceProperties failed"); }
+    a->numCUs = prop.multiProcessorCount;
+
+    st = upload(&a->dTriPairs, a->tri.pairs.data(), a->tri.pairs.size() * sizeof(yart::DevNodePair), a->deviceBytes);
+    if (st == YART_OK) st = upload(&a->dTriAccel, a->tri.triaccel.data(), a->tri.triaccel.size() * sizeof(YartTriAccel), a->deviceBytes);
+    if (st == YART_OK) st = upload(&a->dSphPairs, sph.pairs.data(), sph.pairs.size() * sizeof(yart::DevNodePair), a->deviceBytes);
+    if (st == YART_OK) st = upload(&a->dSphRecs, sph.records.data(), sph.records.size() * sizeof(float), a->deviceBytes);
+    if (st == YART_OK) st = upload(&a->dSphIndex, sph.index.data(), sph.index.size() * sizeof(uint32_t), a->deviceBytes);
+    if (st == YART_OK) {
+        hipError_t e = hipMalloc(&a->dCounters, 256 * kCounterSlots);
+        if (e != hipSuccess) st = fail(YART_ERR_OUT_OF_MEMORY, "hipMalloc(counters) failed");
+        else if ((e = hipMemset(a->dCounters, 0, 256 * kCounterSlots)) != hipSuccess) st = failHip(e, "hipMemset");
+        else a->deviceBytes += 256 * kCounterSlots;
+    }
+    if (st != YART_OK) { yart_accel_destroy(a); return st; }
+    // the device copy is authoritative from here on; the pair array is not needed on the host
+    a->tri.pairs.clear();
+    a->tri.pairs.shrink_to_fit();
+    *out = a;
+    return YART_OK;
+}
+
+void yart_accel_destroy(YartAccel* a)
+{
+    if (!a) return;
+    {
+        DeviceGuard guard(a->device);
+        (void)hipFree(a->dTriPairs);
+        (void)hipFree(a->dTriAccel);
+        (void)hipFree(a->dSphPairs);
+        (void)hipFree(a->dSphRecs);
+        (void)hipFree(a->dSphIndex);
+        (void)hipFree(a->dCounters);
+    }
+    delete a;
+}
+
+int yart_intersect_closest_dev(YartAccel* accel, const YartRay* d_rays, size_t n, YartHit* d_hits,
+                               unsigned flags, void* stream)
+{
+    return run(accel, Launch{ false, false, d_rays, n, d_hits, nullptr, nullptr, flags, static_cast<hipStream_t>(stream) });
+}
+
+int yart_intersect_any_dev(YartAccel* accel, const YartRay* d_rays, size_t n, uint8_t* d_occluded,
+                           unsigned flags, void* stream)
+{
+    return run(accel, Launch{ true, false, d_rays, n, nullptr, d_occluded, nullptr, flags, static_cast<hipStream_t>(stream) });
+}
+
+int yart_intersect_closest_counted_dev(YartAccel* accel, const YartRay* d_rays, size_t n, YartHit* d_hits,
+                                       uint32_t* d_counts, unsigned flags, void* stream)
+{
+    return run(accel, Launch{ false, true, d_rays, n, d_hits, nullptr, d_counts, flags, static_cast<hipStream_t>(stream) });
+}
+
+int yart_intersect_any_counted_dev(YartAccel* accel, const YartRay* d_rays, size_t n, uint8_t* d_occluded,
+                                   uint32_t* d_counts, unsigned flags, void* stream)
+{
+    return run(accel, Launch{ true, true, d_rays, n, nullptr, d_occluded, d_counts, flags, static_cast<hipStream_t>(stream) });
+}
+
+static int hostCall(YartAccel* accel, const YartRay* rays, size_t n, YartHit* hits, uint8_t* occluded, unsigned flags)
+{
+    if (!accel) return fail(YART_ERR_INVALID_ARGUMENT, "null accel");
+    if (n == 0) return YART_OK;
+    if (!rays || (!hits && !occluded)) return fail(YART_ERR_INVALID_ARGUMENT, "null ray / result pointer");
+    DeviceGuard guard(accel->device);
+    if (!guard.ok) return fail(YART_ERR_NO_DEVICE, "hipSetDevice failed");
+    void* dRays = nullptr;
+    void* dOut = nullptr;
+    const size_t outBytes = hits ? n * sizeof(YartHit) : n;
+    hipError_t e = hipMalloc(&dRays, n * sizeof(YartRay));
+    if (e == hipSuccess) e = hipMalloc(&dOut, outBytes);
+    int st = YART_OK;
+    if (e != hipSuccess) st = fail(YART_ERR_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e));
+    if (st == YART_OK && (e = hipMemcpy(dRays, rays, n * sizeof(YartRay), hipMemcpyHostToDevice)) != hipSuccess)
+        st = failHip(e, "hipMemcpy H2D");
+    if (st == YART_OK) {
+        st = hits ? yart_intersect_closest_dev(accel, static_cast<YartRay*>(dRays), n, static_cast<YartHit*>(dOut), flags, nullptr)
+                  : yart_intersect_any_dev(accel, static_cast<YartRay*>(dRays), n, static_cast<uint8_t*>(dOut), flags, nullptr);
+    }
+    if (st == YART_OK && (e = hipMemcpy(hits ? static_cast<void*>(hits) : static_cast<void*>(occluded), dOut, outBytes,
+                                        hipMemcpyDeviceToHost)) != hipSuccess)
+        st = failHip(e, "hipMemcpy D2H");
+    (void)hipFree(dRays);
+    (void)hipFree(dOut);
+    return st;
+}
+
+int yart_intersect_closest(YartAccel* accel, const YartRay* rays, size_t n, YartHit* hits, unsigned flags)
+{
+    if (!hits && n) return fail(YART_ERR_INVALID_ARGUMENT, "hits is null");
+    return hostCall(accel, rays, n, hits, nullptr, flags);
+}
+
+int yart_intersect_any(YartAccel* accel, const YartRay* rays, size_t n, uint8_t* occluded, unsigned flags)
+{
+    if (!occluded && n) return fail(YART_ERR_INVALID_ARGUMENT, "occluded is null");
+    return hostCall(accel, rays, n, nullptr, occluded, flags);
+}
+
+size_t yart_accel_num_nodes(const YartAccel* a) { return a ? a->tri.nodes.size() : 0; }
+size_t yart_accel_num_triangles(const YartAccel* a) { return a ? a->tri.triaccel.size() : 0; }
+size_t yart_accel_num_spheres(const YartAccel* a) { return a ? a->numSpheres : 0; }
+int yart_accel_depth(const YartAccel* a) { return a ? a->tri.depth : 0; }
+size_t yart_accel_device_bytes(const YartAccel* a) { return a ? a->deviceBytes : 0; }
+
+int yart_accel_get_nodes(const YartAccel* a, YartBvhNode* out)
+{
+    if (!a || !out) return fail(YART_ERR_INVALID_ARGUMENT, "null argument");
+    std::memcpy(out, a->tri.nodes.data(), a->tri.nodes.size() * sizeof(YartBvhNode));
+    return YART_OK;
+}
+
+int yart_accel_get_triaccel(const YartAccel* a, YartTriAccel* out)
+{
+    if (!a || !out) return fail(YART_ERR_INVALID_ARGUMENT, "null argument");
+    std::memcpy(out, a->tri.triaccel.data(), a->tri.triaccel.size() * sizeof(YartTriAccel));
+    return YART_OK;
+}
+
+int yart_build_host(const float* verts, size_t n_verts, const int32_t* tris, size_t n_tris,
+                    YartBvhNode* nodes_out, size_t* n_nodes, YartTriAccel* triaccel_out)
+{
+    yart::TriangleBvh bvh;
+    std::string err;
+    const int st = yart::buildTriangleBvh(verts, n_verts, tris, n_tris, bvh, err);
+    if (st != YART_OK) return fail(st, err);
+    if (n_nodes) *n_nodes = bvh.nodes.size();
+    if (nodes_out) std::memcpy(nodes_out, bvh.nodes.data(), bvh.nodes.size() * sizeof(YartBvhNode));
+    if (triaccel_out) std::memcpy(triaccel_out, bvh.triaccel.data(), bvh.triaccel.size() * sizeof(YartTriAccel));
+    return YART_OK;
+}
+
+const char* yart_status_string(int status)
+{
+    switch (status) {
+    case YART_OK: return "ok";
+    case YART_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case YART_ERR_NO_DEVICE: return "no HIP device";
+    case YART_ERR_HIP: return "HIP runtime error";
+    case YART_ERR_OUT_OF_MEMORY: return "out of memory";
+    case YART_ERR_TREE_TOO_DEEP: return "BVH too deep";
+    default: return "unknown status";
+    }
+}
+
+const char* yart_last_error(void) { return g_lastError.c_str(); }
+
+} // extern "C"
