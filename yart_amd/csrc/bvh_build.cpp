@@ -168,7 +168,7 @@ void emitPairs(const FlatTree& t, const std::vector<uint32_t>& slotOfLeaf, std::
     std::memset(&empty, 0, sizeof empty);
     const float inf = std::numeric_limits<float>::infinity();
     for (int a = 0; a < 3; ++a) { empty.lo[a] = inf; empty.hi[a] = -inf; }
-    empty.ref = kEmptyLeaf;
+    empty.ref = kPadLeaf;
     empty.split_axis = 3;
     pairs[0].child[0] = record(0);
     pairs[0].child[1] = empty;

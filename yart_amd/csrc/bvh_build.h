@@ -40,7 +40,10 @@ static_assert(sizeof(DevNodeRec) == 32, "device node record is 32 bytes");
 static_assert(sizeof(DevNodePair) == 64, "device node pair is 64 bytes");
 
 constexpr uint32_t kLeafBit = 0x80000000u;
-constexpr uint32_t kEmptyLeaf = kLeafBit;            // leaf with zero primitives
+constexpr uint32_t kEmptyLeaf = kLeafBit;            // leaf with zero primitives at slot 0: doubles as the
+                                                     // kernel's "lane has no node" marker
+constexpr uint32_t kPadLeaf = kLeafBit | (1u << 3);  // the empty leaf next to the root in pair 0 (slot 1,
+                                                     // zero primitives): distinct from kEmptyLeaf
 constexpr uint32_t kMaxPairs = 1u << 29;
 constexpr uint32_t kMaxLeafSlot = 1u << 28;
 constexpr int kMaxDepth = 64;                        // src/bvhaccel.cpp:244

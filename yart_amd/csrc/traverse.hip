@@ -112,6 +112,9 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceParams P)
         r.ox = a.x; r.oy = a.y; r.oz = a.z; r.tmin = a.w;
         r.dx = b.x; r.dy = b.y; r.dz = b.z; r.tmax = b.w;
         r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
+        // The reference's sphere loop never looks at ray.minT (include/sphere.h:63-97 accepts
+        // any t in (1e-4, current t)); only its triangle BVH culls by it (include/bbox.h:32,49).
+        if (PRIM == 1) r.tmin = 0.0f;
         tcur = r.tmax; hu = 0.0f; hv = 0.0f; prim = -1; minS = -1; maxL = -1; occ = 0;
         cNodes = 0; cPrims = 0;
         sp = 0;
