@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""bench.py -- closest-hit throughput of the MI355X intersection engine.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path -- coherence sort + sphere-tree pass +
+triangle-tree pass (yart_intersect_closest_dev) -- over one batch of synthetic rays
+already resident in HBM.  Workload at N=1 (BASELINE.json configs[3], the config the
+metric "Mrays/sec (closest-hit, incoherent paths)" is quoted on; it fits one GPU):
+10 M-triangle random soup + 1 M spheres, 2^24 uniformly random rays (SURVEY.md 8d
+C4).  With N ranks the scene is replicated on every GPU and every rank traces its own
+batch of the same size (weak scaling, no data-path collective: rays are independent).
+
+Prints ONE JSON line on rank 0 (metric/value/... + "roofline" + "cpu_baseline").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def algorithmic_bytes(counts, chained):
+    """32 B ray in + 16 B hit out + 32 B per node record + 48 B per
+    triangle record + 16 B per sphere record fetched, per ray and per kernel.
+    counts: [n,4] = tri-tree node records, triangle records, sphere-tree node records,
+    sphere records (the engine's own deterministic traversal, counting kernel)."""
+    c = counts.sum(0).astype(np.float64)
+    n = float(len(counts))
+    tri = n * (32 + 16 + (16 if chained else 0)) + 32.0 * c[0] + 48.0 * c[1]
+    sph = (n * (32 + 16) + 32.0 * c[2] + 16.0 * c[3]) if chained else 0.0
+    return tri, sph
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--tris", type=int, default=10_000_000)
+    ap.add_argument("--spheres", type=int, default=1_000_000)
+    ap.add_argument("--rays", type=int, default=1 << 24)
+    ap.add_argument("--s", type=float, default=0.005, help="soup edge scale (SURVEY.md 8d sweeps 0.002/0.005/0.01)")
+    ap.add_argument("--no-sort", action="store_true")
+    ap.add_argument("--static", action="store_true", help="plain grid launch instead of the persistent kernel")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget; 0 disables it")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from yart_amd import api, scenes
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    t0 = time.time()
+    verts, tris, sph = scenes.random_soup(args.tris, args.spheres, s=args.s, seed=42)
+    rays = scenes.random_rays(args.rays, seed=7 + rank)
+    t1 = time.time()
+    acc = api.Accel(verts, tris, sph, device=local_rank)
+    t2 = time.time()
+    if rank == 0:
+        log("scene: %d tris, %d spheres, %d nodes, depth %d, %.1f MB in HBM (gen %.1fs, build+upload %.1fs)"
+            % (acc.num_triangles, acc.num_spheres, acc.num_nodes, acc.depth, acc.device_bytes / 1e6, t1 - t0, t2 - t1))
+    d_rays = torch.from_numpy(rays).cuda()
+    d_hits = torch.empty((args.rays, 4), dtype=torch.float32, device="cuda")
+    flags = 0
+    if not args.no_sort:
+        flags |= api.YART_SORT_RAYS
+    if args.static:
+        flags |= api.YART_STATIC_LAUNCH
+
+    # ---- fetch counts of the engine's own traversal -> algorithmic bytes per launch
+    d_counts = torch.zeros((args.rays, 4), dtype=torch.int32, device="cuda")
+    acc.intersect_closest(d_rays, flags, out=d_hits, counts=d_counts)
+    torch.cuda.synchronize()
+    counts = d_counts.cpu().numpy().astype(np.uint32)
+    del d_counts
+    bytes_tri, bytes_sph = algorithmic_bytes(counts, acc.num_spheres > 0)
+    mean_counts = counts.mean(0)
+    counted_hits = d_hits.clone()
+
+    # ---- warm-up, then the timed region
+    for _ in range(args.warmup):
+        acc.intersect_closest(d_rays, flags, out=d_hits)
+    torch.cuda.synchronize()
+    acc.profile(True)
+    acc.profile_read()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    tic = time.perf_counter()
+    for _ in range(args.steps):
+        acc.intersect_closest(d_rays, flags, out=d_hits)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - tic
+    prof = acc.profile_read()
+    acc.profile(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- size-independent properties at full size (parity gate, part 1)
+    same_as_counted = bool(torch.equal(d_hits.view(torch.int32), counted_hits.view(torch.int32)))            # idempotent / counting variant agrees
+    plain = acc.intersect_closest(d_rays, api.YART_STATIC_LAUNCH)        # unsorted, static grid
+    a, b = api.hits_to_numpy(d_hits), api.hits_to_numpy(plain)
+    order_independent = bool(np.array_equal(a["prim"], b["prim"]) and np.array_equal(a["t"].view(np.uint32), b["t"].view(np.uint32)))
+    d_occ = acc.intersect_any(d_rays, flags)
+    any_consistent = bool(np.array_equal(d_occ.cpu().numpy() != 0, a["prim"] != -1))
+    hit_frac = float((a["prim"] != -1).mean())
+    del plain, d_occ, counted_hits
+
+    value = world * args.rays * args.steps / elapsed / 1e6
+    out = {
+        "metric": "Mrays/sec (closest-hit, incoherent paths)",
+        "value": round(value, 2),
+        "unit": "Mrays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32 (f64 sphere test)",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE configs[3]: random soup %d tris (s=%g) + %d spheres, %d uniformly random rays per GPU, "
+                        "closest-hit, sort=%s, launch=%s" % (args.tris, args.s, args.spheres, args.rays,
+                                                             "off" if args.no_sort else "morton+octant",
+                                                             "static" if args.static else "persistent"),
+            "rays_per_gpu": args.rays, "tris": args.tris, "spheres": args.spheres,
+            "scene_replicated": True, "hit_fraction": round(hit_frac, 4),
+        },
+    }
+    t_tri = prof["ms_triangles"] / max(1, args.steps) * 1e-3
+    t_sph = prof["ms_spheres"] / max(1, args.steps) * 1e-3
+    t_sort = prof["ms_sort"] / max(1, args.steps) * 1e-3
+    achieved = bytes_tri / t_tri / 1e9 if t_tri > 0 else 0.0
+    out["roofline"] = {
+        "bound": "hbm",
+        "kernel": "traceKernel<triangles, closest, pruned> (yart_amd/csrc/traverse.hip)",
+        "achieved": round(achieved, 1),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": None,
+        "algorithmic_bytes_per_launch": int(bytes_tri),
+        "algorithmic_bytes_per_ray": round(bytes_tri / args.rays, 1),
+        "kernel_ms": round(t_tri * 1e3, 3),
+        "per_ray_fetches": {"tri_tree_node_records": round(float(mean_counts[0]), 2),
+                            "triangle_records": round(float(mean_counts[1]), 2),
+                            "sphere_tree_node_records": round(float(mean_counts[2]), 2),
+                            "sphere_records": round(float(mean_counts[3]), 2)},
+        "other_kernels_ms": {"sort": round(t_sort * 1e3, 3), "sphere_tree": round(t_sph * 1e3, 3)},
+        "sphere_kernel_achieved_GBs": round(bytes_sph / t_sph / 1e9, 1) if t_sph > 0 else None,
+    }
+    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(traffic_file):
+        try:
+            tr = json.load(open(traffic_file))
+            key = "tris=%d,spheres=%d,rays=%d,s=%g" % (args.tris, args.spheres, args.rays, args.s)
+            if key in tr:
+                out["roofline"]["traffic"] = tr[key]["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = tr[key].get("source")
+        except Exception as exc:     # a malformed side file must not break the bench line
+            log("traffic.json ignored: %r" % (exc,))
+    out["parity_gate"] = {"idempotent_and_counting_variant_equal": same_as_counted,
+                          "sorted_persistent_equals_unsorted_static": order_independent,
+                          "any_hit_consistent_with_closest": any_consistent}
+
+    # ---- CPU baseline + sampled parity against it (rank 0, N=1 only)
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        out["cpu_baseline"], out["parity_gate"]["sample_vs_cpu"] = cpu_baseline(
+            verts, tris, sph, rays, a, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(verts, tris, sph, rays, gpu_hits, budget_s):
+    """The reference's own Scene::intersect (oracle/_ref, compiled from /root/reference in
+    the authoring container) -- or, if that build is absent, the oracle restatement -- on a
+    bounded sample of the SAME workload, all host threads.  Also the sampled parity check:
+    the GPU results for those rays against the CPU's."""
+    from oracle import oracle as orc
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1))
+    kind = "reference" if os.path.exists(orc.REF_SO) else "port"
+    t0 = time.time()
+    if kind == "reference":
+        cpu = orc.Reference(verts, tris, sph, gen_normals=False)
+        run = lambda r: cpu.throughput(r, cores)
+    else:
+        cpu = orc.Oracle(verts, tris, sph)
+        run = lambda r: cpu.intersect(r, 0, nthreads=cores)["t"]
+    log("cpu baseline (%s) scene build %.1fs, %d threads" % (kind, time.time() - t0, cores))
+    n = 256
+    while True:                                   # grow the sample until it costs about budget_s
+        t0 = time.perf_counter()
+        t_cpu = run(rays[:n])
+        dt = max(time.perf_counter() - t0, 1e-4)
+        if dt >= budget_s / 3 or n >= len(rays):
+            break
+        n = min(len(rays), 1 << int(np.log2(n * min(64.0, max(2.0, 0.8 * budget_s / dt)))))
+    mrays = n / dt / 1e6
+    g = gpu_hits[:n]
+    hit_equal = bool(np.array_equal(np.isfinite(t_cpu) & (t_cpu < rays[:n, 7]), g["prim"] != -1))
+    m = g["prim"] != -1
+    rel = np.abs(g["t"][m] - t_cpu[m]) / np.abs(t_cpu[m])
+    parity = {"rays": n, "hit_miss_equal": hit_equal,
+              "t_bit_equal_fraction": float((g["t"].view(np.uint32) == t_cpu.view(np.uint32)).mean()),
+              "max_rel_t_err": float(rel.max()) if rel.size else 0.0}
+    base = {"value": round(mrays, 6), "unit": "Mrays/s", "cores": cores, "kind": kind,
+            "sample": "first %d rays of the same batch, same scene (10M-class soup incl. the O(#spheres) linear sphere "
+                      "loop of include/scene.h:142-144), %.1f s wall" % (n, dt)}
+    # the same sample without spheres: the BVH part alone (BASELINE.md plan)
+    if len(sph):
+        del cpu
+        if kind == "reference":
+            cpu2 = orc.Reference(verts, tris, np.zeros((0, 4), np.float32), gen_normals=False)
+            run2 = lambda r: cpu2.throughput(r, cores)
+        else:
+            cpu2 = orc.Oracle(verts, tris, np.zeros((0, 4), np.float32))
+            run2 = lambda r: cpu2.intersect(r, 0, nthreads=cores)["t"]
+        n2 = 1 << 12
+        while True:
+            t0 = time.perf_counter()
+            run2(rays[:n2])
+            dt2 = max(time.perf_counter() - t0, 1e-4)
+            if dt2 >= budget_s / 6 or n2 >= len(rays):
+                break
+            n2 = min(len(rays), 1 << int(np.log2(n2 * min(64.0, max(2.0, 0.4 * budget_s / dt2)))))
+        base["triangles_only"] = {"value": round(n2 / dt2 / 1e6, 6), "unit": "Mrays/s",
+                                  "sample": "first %d rays, spheres removed, %.1f s wall" % (n2, dt2)}
+    return base, parity
+
+
+if __name__ == "__main__":
+    main()

@@ -130,10 +130,12 @@ int yart_intersect_closest_dev(YartAccel* accel, const YartRay* d_rays, size_t n
 int yart_intersect_any_dev(YartAccel* accel, const YartRay* d_rays, size_t n,
                            uint8_t* d_occluded, unsigned flags, void* stream);
 
-/* As above and additionally writes, per ray, three uint32 fetch counters:
- * 32-byte node records fetched, 48-byte triangle records tested, 16-byte
- * sphere records tested -- the terms of the algorithmic bytes per ray
- * (SURVEY.md 8d).  Diagnostic; slower. */
+/* As above and additionally writes, per ray, FOUR uint32 fetch counters:
+ *   [0] 32-byte node records fetched from the triangle tree
+ *   [1] 48-byte triangle records tested
+ *   [2] 32-byte node records fetched from the sphere tree
+ *   [3] 16-byte sphere records tested
+ * -- the terms of the algorithmic bytes per ray.  Diagnostic; slower. */
 int yart_intersect_closest_counted_dev(YartAccel* accel, const YartRay* d_rays, size_t n,
                                        YartHit* d_hits, uint32_t* d_counts,
                                        unsigned flags, void* stream);
@@ -170,6 +172,16 @@ int yart_build_host(const float* verts, size_t n_verts,
                     const int32_t* tris, size_t n_tris,
                     YartBvhNode* nodes_out, size_t* n_nodes,
                     YartTriAccel* triaccel_out);
+
+/* Per-kernel timing (no counterpart in the reference, which only has a wall-clock
+ * Timer around the whole render, include/timer.h:6-26).  While enabled, every
+ * intersect call brackets its sort, sphere-tree and triangle-tree launches with HIP
+ * events on the caller's stream; yart_accel_profile_read synchronises those events,
+ * adds their durations (milliseconds) and launch counts to the outputs and clears
+ * the list.  Not thread-safe; diagnostic. */
+int yart_accel_profile_enable(YartAccel* accel, int enable);
+int yart_accel_profile_read(YartAccel* accel, double* ms_sort, double* ms_spheres,
+                            double* ms_triangles, uint64_t* n_calls);
 
 const char* yart_status_string(int status);
 /* Text of the last failure on the calling thread ("" if none). */

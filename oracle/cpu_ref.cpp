@@ -479,8 +479,8 @@ void orc_get_leaf_order(void* h, uint32_t* out)
 // mode 0: reference rule (Scene::intersect exactly)
 // mode 1: engine rule for the triangle BVH (pruned, pair-wise box tests),
 //         spheres still the reference's linear loop
-// counts (optional): 3 x uint32 per ray = 32-byte node records fetched,
-//         triangle records tested, spheres tested
+// counts (optional): 4 x uint32 per ray = triangle-tree node records fetched,
+//         triangle records tested, 0 (the oracle has no sphere tree), spheres tested
 void orc_intersect(void* h, const float* rays, size_t n, void* hitsOut, uint32_t* counts,
                    int mode, int nthreads)
 {
@@ -505,7 +505,7 @@ void orc_intersect(void* h, const float* rays, size_t n, void* hitsOut, uint32_t
             }
             if (hit.prim == -1) { hit.u = 0.0f; hit.v = 0.0f; }
             out[i] = hit;
-            if (counts) { counts[i * 3] = c.nodes; counts[i * 3 + 1] = c.tris; counts[i * 3 + 2] = c.spheres; }
+            if (counts) { counts[i * 4] = c.nodes; counts[i * 4 + 1] = c.tris; counts[i * 4 + 2] = 0; counts[i * 4 + 3] = c.spheres; }
         }
     });
 }
@@ -533,7 +533,7 @@ void orc_intersect_shadow(void* h, const float* rays, size_t n, uint8_t* out, ui
                 }
             }
             out[i] = occ ? 1 : 0;
-            if (counts) { counts[i * 3] = c.nodes; counts[i * 3 + 1] = c.tris; counts[i * 3 + 2] = c.spheres; }
+            if (counts) { counts[i * 4] = c.nodes; counts[i * 4 + 1] = c.tris; counts[i * 4 + 2] = 0; counts[i * 4 + 3] = c.spheres; }
         }
     });
 }

@@ -109,14 +109,14 @@ class Oracle:
     def intersect(self, rays, mode=0, counts=False, nthreads=8):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
         hits = np.zeros(len(rays), HIT_DTYPE)
-        cnt = np.zeros((len(rays), 3), np.uint32) if counts else None
+        cnt = np.zeros((len(rays), 4), np.uint32) if counts else None
         self.lib.orc_intersect(self.h, _p(rays), len(rays), _p(hits), _p(cnt), mode, nthreads)
         return (hits, cnt) if counts else hits
 
     def intersect_shadow(self, rays, mode=0, counts=False, nthreads=8):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
         occ = np.zeros(len(rays), np.uint8)
-        cnt = np.zeros((len(rays), 3), np.uint32) if counts else None
+        cnt = np.zeros((len(rays), 4), np.uint32) if counts else None
         self.lib.orc_intersect_shadow(self.h, _p(rays), len(rays), _p(occ), _p(cnt), mode, nthreads)
         return (occ, cnt) if counts else occ
 

@@ -89,14 +89,13 @@ def test_fetch_counters_match_cpu_counting_oracle(golden, accel):
     o = orc.Oracle(golden["verts"], golden["tris"], golden["spheres"])
     _, want = o.intersect(golden["rays"], mode=1, counts=True)
     rays = dev(golden["rays"])
-    counts = torch.zeros((len(golden["rays"]), 3), dtype=torch.int32, device="cuda")
+    counts = torch.zeros((len(golden["rays"]), 4), dtype=torch.int32, device="cuda")
     hits = api.hits_to_numpy(accel.intersect_closest(rays, 0, counts=counts))
     got = counts.cpu().numpy().astype(np.uint32)
     assert_within_bar(hits, golden["prim"], golden["t"])
-    if len(golden["spheres"]) == 0:
-        assert np.array_equal(got[:, 0], want[:, 0])
+    assert np.array_equal(got[:, 0], want[:, 0])           # triangle-tree node records fetched
     assert np.array_equal(got[:, 1], want[:, 1])           # triangle records tested
-    assert (got[:, 2] <= want[:, 2]).all()                 # sphere BVH never tests more than the linear loop
+    assert (got[:, 3] <= want[:, 3]).all()                 # sphere tree never tests more than the linear loop
     _, want_any = o.intersect_shadow(golden["shadow_rays"], mode=1, counts=True)
     counts.zero_()
     accel.intersect_any(dev(golden["shadow_rays"]), 0, counts=counts)

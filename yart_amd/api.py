@@ -33,6 +33,7 @@ EXPORTS = [
     "yart_accel_num_nodes", "yart_accel_num_triangles", "yart_accel_num_spheres",
     "yart_accel_get_nodes", "yart_accel_get_triaccel", "yart_accel_depth",
     "yart_accel_device_bytes", "yart_build_host", "yart_status_string", "yart_last_error",
+    "yart_accel_profile_enable", "yart_accel_profile_read",
 ]
 
 _vp = ctypes.c_void_p
@@ -70,6 +71,9 @@ def lib():
     L.yart_accel_get_nodes.argtypes = [_vp, _vp]
     L.yart_accel_get_triaccel.argtypes = [_vp, _vp]
     L.yart_build_host.argtypes = [_vp, _sz, _vp, _sz, _vp, ctypes.POINTER(_sz), _vp]
+    L.yart_accel_profile_enable.argtypes = [_vp, ctypes.c_int]
+    L.yart_accel_profile_read.argtypes = [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                          ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
     L.yart_status_string.argtypes = [ctypes.c_int]
     L.yart_status_string.restype = ctypes.c_char_p
     L.yart_last_error.restype = ctypes.c_char_p
@@ -164,6 +168,17 @@ class Accel:
         if out.size:
             _check(lib().yart_accel_get_triaccel(self._h, _p(out)))
         return out
+
+    def profile(self, enable=True):
+        _check(lib().yart_accel_profile_enable(self._h, 1 if enable else 0))
+
+    def profile_read(self):
+        """-> dict(ms_sort, ms_spheres, ms_triangles, calls): HIP-event time of each kernel
+        group since the last read, measured on the stream the kernels were launched on."""
+        a, b, c, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_uint64()
+        _check(lib().yart_accel_profile_read(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c),
+                                             ctypes.byref(n)))
+        return dict(ms_sort=a.value, ms_spheres=b.value, ms_triangles=c.value, calls=n.value)
 
     # -- device-resident batches (torch tensors on this accel's GPU) --------
     def _stream(self, stream):

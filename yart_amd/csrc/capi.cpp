@@ -9,6 +9,7 @@
 #include <limits>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/yart_amd.h"
 #include "bvh_build.h"
@@ -50,6 +51,11 @@ struct YartAccel {
     void* dCounters = nullptr;
     size_t deviceBytes = 0;
     std::atomic<unsigned> nextCounter{ 0 };
+    // per-kernel timing (yart_accel_profile_*): kind 0 = sort, 1 = sphere tree, 2 = triangle tree
+    struct Span { hipEvent_t start, stop; int kind; };
+    bool profile = false;
+    std::vector<Span> spans;
+    uint64_t profiledCalls = 0;
 
     uint32_t* counterSlot()
     {
@@ -82,6 +88,26 @@ int upload(void** dst, const void* src, size_t bytes, size_t& total)
     total += bytes;
     return YART_OK;
 }
+
+// Brackets one launch with events when profiling is on.
+struct ScopedSpan {
+    YartAccel* a;
+    hipStream_t stream;
+    YartAccel::Span span;
+    bool on;
+    ScopedSpan(YartAccel* accel, int kind, hipStream_t s) : a(accel), stream(s), on(accel->profile)
+    {
+        span.kind = kind;
+        if (on) {
+            on = hipEventCreate(&span.start) == hipSuccess && hipEventCreate(&span.stop) == hipSuccess &&
+                 hipEventRecord(span.start, stream) == hipSuccess;
+        }
+    }
+    ~ScopedSpan()
+    {
+        if (on && hipEventRecord(span.stop, stream) == hipSuccess) a->spans.push_back(span);
+    }
+};
 
 struct Launch {
     bool any, count;
@@ -118,8 +144,11 @@ int run(YartAccel* a, const Launch& L)
         hipError_t e = hipMallocAsync(&sortWs, wsBytes + permBytes, L.stream);
         if (e != hipSuccess) return fail(YART_ERR_OUT_OF_MEMORY, std::string("hipMallocAsync: ") + hipGetErrorString(e));
         perm = reinterpret_cast<uint32_t*>(static_cast<char*>(sortWs) + wsBytes);
-        e = yart::sortRays(reinterpret_cast<const float4*>(L.rays), n, a->sceneLo, a->sceneHi, perm,
-                           sortWs, wsBytes, L.stream);
+        {
+            ScopedSpan span(a, 0, L.stream);
+            e = yart::sortRays(reinterpret_cast<const float4*>(L.rays), n, a->sceneLo, a->sceneHi, perm,
+                               sortWs, wsBytes, L.stream);
+        }
         if (e != hipSuccess) { (void)hipFreeAsync(sortWs, L.stream); return failHip(e, "sortRays"); }
     }
 
@@ -140,6 +169,7 @@ int run(YartAccel* a, const Launch& L)
         P.primIndex = static_cast<const uint32_t*>(a->dSphIndex);
         P.workCounter = a->counterSlot();
         P.chained = 0;
+        ScopedSpan span(a, 1, L.stream);
         e = yart::launchTrace(P, 1, L.any, prune, L.count, persistent, a->numCUs, L.stream);
     }
     if (e == hipSuccess) {
@@ -148,9 +178,11 @@ int run(YartAccel* a, const Launch& L)
         P.primIndex = nullptr;
         P.workCounter = a->counterSlot();
         P.chained = a->numSpheres > 0 ? 1u : 0u;
+        ScopedSpan span(a, 2, L.stream);
         e = yart::launchTrace(P, 0, L.any, prune, L.count, persistent, a->numCUs, L.stream);
     }
     if (sortWs) (void)hipFreeAsync(sortWs, L.stream);
+    if (a->profile) a->profiledCalls++;
     if (e != hipSuccess) return failHip(e, "traversal launch");
     return YART_OK;
 }
@@ -328,6 +360,38 @@ int yart_build_host(const float* verts, size_t n_verts, const int32_t* tris, siz
     if (nodes_out) std::memcpy(nodes_out, bvh.nodes.data(), bvh.nodes.size() * sizeof(YartBvhNode));
     if (triaccel_out) std::memcpy(triaccel_out, bvh.triaccel.data(), bvh.triaccel.size() * sizeof(YartTriAccel));
     return YART_OK;
+}
+
+int yart_accel_profile_enable(YartAccel* a, int enable)
+{
+    if (!a) return fail(YART_ERR_INVALID_ARGUMENT, "null accel");
+    a->profile = enable != 0;
+    return YART_OK;
+}
+
+int yart_accel_profile_read(YartAccel* a, double* ms_sort, double* ms_spheres, double* ms_triangles,
+                            uint64_t* n_calls)
+{
+    if (!a) return fail(YART_ERR_INVALID_ARGUMENT, "null accel");
+    DeviceGuard guard(a->device);
+    double ms[3] = { 0.0, 0.0, 0.0 };
+    int st = YART_OK;
+    for (auto& s : a->spans) {
+        float t = 0.0f;
+        hipError_t e = hipEventSynchronize(s.stop);
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, s.start, s.stop);
+        if (e != hipSuccess) st = failHip(e, "profile event");
+        else ms[s.kind] += t;
+        (void)hipEventDestroy(s.start);
+        (void)hipEventDestroy(s.stop);
+    }
+    a->spans.clear();
+    if (ms_sort) *ms_sort = ms[0];
+    if (ms_spheres) *ms_spheres = ms[1];
+    if (ms_triangles) *ms_triangles = ms[2];
+    if (n_calls) *n_calls = a->profiledCalls;
+    a->profiledCalls = 0;
+    return st;
 }
 
 const char* yart_status_string(int status)

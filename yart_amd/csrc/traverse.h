@@ -16,7 +16,7 @@ struct TraceParams {
     uint32_t n;
     float4* hits;               // closest-hit output (YartHit)
     uint8_t* occluded;          // any-hit output
-    uint32_t* counts;           // optional 3 x uint32 per ray
+    uint32_t* counts;           // optional 4 x uint32 per ray (see include/yart_amd.h)
     uint32_t* workCounter;      // persistent launch: 256-byte slot, zeroed by the launcher
     uint32_t chained;           // 1: a sphere pass already initialised hits/occluded/counts
 };

@@ -261,9 +261,9 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceParams P)
                 P.hits[rayId] = make_float4(tcur, hu, hv, __int_as_float(prim));
             }
             if (COUNT) {
-                uint32_t* c = P.counts + (size_t)rayId * 3;
-                if (P.chained) { c[0] += cNodes; c[1 + PRIM] += cPrims; }
-                else { c[0] = cNodes; c[1 + PRIM] = cPrims; c[2 - PRIM] = 0; }
+                uint32_t* c = P.counts + (size_t)rayId * 4;
+                c[2 * PRIM] = cNodes; c[2 * PRIM + 1] = cPrims;
+                if (!P.chained) { c[2 - 2 * PRIM] = 0; c[3 - 2 * PRIM] = 0; }
             }
         }
     }
