@@ -5,6 +5,7 @@
 
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -56,6 +57,8 @@ struct YartAccel {
     bool profile = false;
     std::vector<Span> spans;
     uint64_t profiledCalls = 0;
+    // scheduling knobs of the persistent kernel (YART_REFILL_MIN / YART_NODE_MIN override)
+    uint32_t refillMin = 16, nodeMin = 24;
 
     uint32_t* counterSlot()
     {
@@ -160,10 +163,12 @@ int run(YartAccel* a, const Launch& L)
     P.hits = reinterpret_cast<float4*>(L.hits);
     P.occluded = L.occluded;
     P.counts = L.counts;
+    P.refillMin = a->refillMin;
+    P.nodeMin = a->nodeMin;
     hipError_t e = hipSuccess;
     if (a->numSpheres > 0) {
         // Scene::intersect / intersectShadow visit the spheres before the triangle tree
-        // (include/scene.h:142-146, :176-182)
+        // (include/scene.h:142-146, :176-182); the triangle pass starts from the sphere hit.
         P.pairs = static_cast<const float4*>(a->dSphPairs);
         P.prims = static_cast<const float4*>(a->dSphRecs);
         P.primIndex = static_cast<const uint32_t*>(a->dSphIndex);
@@ -204,6 +209,12 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
     YartAccel* a = new (std::nothrow) YartAccel();
     if (!a) return fail(YART_ERR_OUT_OF_MEMORY, "host allocation failed");
     a->device = device;
+    if (const char* v = std::getenv("YART_REFILL_MIN")) a->refillMin = static_cast<uint32_t>(std::atoi(v));
+    if (const char* v = std::getenv("YART_NODE_MIN")) a->nodeMin = static_cast<uint32_t>(std::atoi(v));
+    if (a->refillMin < 1) a->refillMin = 1;
+    if (a->refillMin > 64) a->refillMin = 64;
+    if (a->nodeMin < 1) a->nodeMin = 1;
+    if (a->nodeMin > 64) a->nodeMin = 64;
     std::string err;
     int st = yart::buildTriangleBvh(verts, n_verts, tris, n_tris, a->tri, err);
     yart::SphereBvh sph;

@@ -17,8 +17,10 @@ struct TraceParams {
     float4* hits;               // closest-hit output (YartHit)
     uint8_t* occluded;          // any-hit output
     uint32_t* counts;           // optional 4 x uint32 per ray (see include/yart_amd.h)
-    uint32_t* workCounter;      // persistent launch: 256-byte slot, zeroed by the launcher
-    uint32_t chained;           // 1: a sphere pass already initialised hits/occluded/counts
+    uint32_t* workCounter;      // persistent launch: 256-byte slot = 8 counters 32 B apart, zeroed by the launcher
+    uint32_t chained;           // 1: triangle pass running after the sphere pass (hits/occluded/counts hold its results)
+    uint32_t refillMin;         // persistent launch: refill a wave once this many lanes are idle
+    uint32_t nodeMin;           // leave the descend loop when fewer lanes than this are at interior nodes
 };
 
 // prim: 0 = triangle tree, 1 = sphere tree.

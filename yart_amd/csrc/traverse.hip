@@ -9,13 +9,24 @@
 // 48 bytes (include/triaccel.h:16-32, test :169-201) or up to 4 spheres of 16
 // bytes (fp64 test, include/sphere.h:63-97).
 //
-// Execution shape: persistent workgroups; every wave pulls chunks of consecutive
-// rays from a global counter and refills idle lanes from its chunk, so lanes that
-// finish early do not idle until the slowest ray of a fixed 64-ray group is done.
+// Pass order is the reference's (include/scene.h:142-146, :176-182): the sphere
+// tree first, then the triangle tree bounded by the sphere hit.
+//
+// Execution shape: persistent workgroups; the batch is cut into 8 ranges (one per
+// XCD) with a counter each; every wave pulls chunks of consecutive rays, its own
+// XCD's range first, and refills idle lanes from its chunk, so lanes that finish
+// early do not idle until the slowest ray of a fixed 64-ray group is done.
 // Per-lane traversal stack: the top kLdsStack entries live in LDS (bank = lane,
 // conflict free for any mix of stack heights), deeper entries spill to scratch.
-// Loop structure is while-while: all lanes descend until none is at an interior
-// node, then all lanes that reached a leaf test its primitives together.
+// Loop structure is while-while: lanes descend until fewer than `nodeMin` of them
+// are at an interior node, then the lanes that reached a leaf test its primitives.
+//
+// What bounds it (measured, profiles/): every lane fetches its own 64-byte pair, so
+// a wave instruction touches up to 64 different cache lines; the vector memory
+// pipe retires about one 16-byte lane request per clock per CU for such scattered
+// loads.  The kernel therefore spends its effort on issuing FEWER 16-byte requests
+// (rows B and C of a triangle record are only fetched once row A has produced a t
+// inside the ray interval) rather than on arithmetic.
 //
 // Arithmetic: built with -ffp-contract=off; every expression rounds exactly as the
 // reference's C++ (no FMA contraction, IEEE division / sqrt), so with
@@ -32,8 +43,7 @@ constexpr int kBlock = 256;          // 4 waves
 constexpr int kLdsStack = 16;        // stack entries per lane kept in LDS
 constexpr int kOvfStack = kMaxDepth - kLdsStack;
 constexpr uint32_t kIdle = kEmptyLeaf;
-constexpr uint32_t kChunk = 256;     // rays a wave takes from the global counter at a time
-constexpr int kRefillMin = 8;        // refill once this many lanes are idle
+constexpr uint32_t kChunk = 256;     // rays a wave takes from a range counter at a time
 
 struct RayState {
     float ox, oy, oz, dx, dy, dz;
@@ -41,12 +51,15 @@ struct RayState {
     float tmin, tmax;
 };
 
-// include/bbox.h:30-50.  `tFar0` is ray.maxT in the reference; the pruned rule
-// passes the current closest t.  The per-axis early-outs of the reference are
-// folded into one final test: tNear only grows, tFar only shrinks and neither can
-// become NaN (NaN operands fail every comparison that would assign them).
-__device__ __forceinline__ bool slab(float lx, float ly, float lz, float hx, float hy, float hz,
-                                     const RayState& r, float tFar0)
+// include/bbox.h:30-50, operation for operation.  `tFar0` is ray.maxT in the
+// reference; the pruned rule passes the current closest t.  The per-axis early-outs
+// of the reference are folded into one final test: tNear only grows, tFar only
+// shrinks and neither can become NaN (NaN operands fail every comparison that would
+// assign them).  The compare/select form keeps the reference's behaviour when a
+// plane distance is NaN (0 * inf: origin on a box plane and a zero direction
+// component).
+__device__ __forceinline__ bool slabExact(float lx, float ly, float lz, float hx, float hy, float hz,
+                                          const RayState& r, float tFar0)
 {
     float tNear = r.tmin, tFar = tFar0;
     float t0, t1, s0, s1;
@@ -62,9 +75,38 @@ __device__ __forceinline__ bool slab(float lx, float ly, float lz, float hx, flo
     return !(tFar < tNear) && (tFar > r.tmin) && (tNear < r.tmax);
 }
 
+// The same test for rays whose six plane distances cannot be NaN (finite origin,
+// finite non-zero 1/dir): every select above then IS a min or a max, so the
+// v_min/v_max/v_min3/v_max3 forms give the same tNear / tFar up to the sign of a
+// zero, which no comparison can see.  Same products, same roundings.
+__device__ __forceinline__ bool slabFast(float lx, float ly, float lz, float hx, float hy, float hz,
+                                         const RayState& r, float tFar0)
+{
+    const float ax = (lx - r.ox) * r.ix, bx = (hx - r.ox) * r.ix;
+    const float ay = (ly - r.oy) * r.iy, by = (hy - r.oy) * r.iy;
+    const float az = (lz - r.oz) * r.iz, bz = (hz - r.oz) * r.iz;
+    const float tNear = fmaxf(fmaxf(r.tmin, fminf(ax, bx)), fmaxf(fminf(ay, by), fminf(az, bz)));
+    const float tFar = fminf(fminf(tFar0, fmaxf(ax, bx)), fminf(fmaxf(ay, by), fmaxf(az, bz)));
+    return !(tFar < tNear) && (tFar > r.tmin) && (tNear < r.tmax);
+}
+
+// first ray of work range `i` of 8 (multiples of kChunk, last range takes the remainder)
+__device__ __forceinline__ uint32_t rangeBegin(uint32_t n, uint32_t i)
+{
+    if (i >= 8) return n;
+    const uint32_t chunks = (n + kChunk - 1) / kChunk;
+    const uint32_t b = (uint32_t)(((uint64_t)chunks * i) / 8) * kChunk;
+    return b < n ? b : n;
+}
+
 __device__ __forceinline__ float sel3(int i, float a, float b, float c)
 {
     return (i == 0) ? a : ((i == 1) ? b : c);
+}
+
+__device__ __forceinline__ bool finiteNonZero(float v)
+{
+    return (v != 0.0f) && (fabsf(v) < __builtin_inff());
 }
 
 template <int PRIM, bool ANY, bool PRUNE, bool COUNT, bool PERSIST>
@@ -82,6 +124,7 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceParams P)
     uint32_t cur = kIdle;            // encoded node reference, see bvh_build.h
     int sp = 0;
     bool live = false;               // lane owns a ray whose result is not written yet
+    bool odd = false;                // this ray needs the NaN-preserving slab test
     uint32_t rayId = 0;
     float tcur = 0.0f, hu = 0.0f, hv = 0.0f;
     int32_t prim = -1;
@@ -93,6 +136,11 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceParams P)
     uint32_t chunkNext = 0, chunkEnd = 0;
     bool exhausted = false;
     bool firstPass = true;
+    // HW_REG_XCC_ID (id 20), bits 3:0 -- which of the 8 XCDs this wave runs on
+    const uint32_t homeXcd = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;
+    uint32_t rangesDone = 0;
+    const int refillMin = (int)P.refillMin;
+    const int nodeMin = (int)P.nodeMin;
 
     auto push = [&](uint32_t v) {
         if (sp < kLdsStack) ldsStack[sp * kBlock + tid] = v;
@@ -115,12 +163,15 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceParams P)
         // The reference's sphere loop never looks at ray.minT (include/sphere.h:63-97 accepts
         // any t in (1e-4, current t)); only its triangle BVH culls by it (include/bbox.h:32,49).
         if (PRIM == 1) r.tmin = 0.0f;
+        odd = !(finiteNonZero(r.ix) && finiteNonZero(r.iy) && finiteNonZero(r.iz) &&
+                fabsf(r.ox) < __builtin_inff() && fabsf(r.oy) < __builtin_inff() && fabsf(r.oz) < __builtin_inff() &&
+                r.tmin == r.tmin && r.tmax == r.tmax);
         tcur = r.tmax; hu = 0.0f; hv = 0.0f; prim = -1; minS = -1; maxL = -1; occ = 0;
         cNodes = 0; cPrims = 0;
         sp = 0;
         live = true;
         cur = 0u;                    // pair 0 = { root, empty leaf }, axis bits 0
-        if (P.chained) {
+        if (P.chained) {             // triangle pass after the sphere pass
             if (ANY) {
                 if (P.occluded[rayId]) { live = false; cur = kIdle; }   // a sphere already occludes
             } else {
@@ -135,13 +186,18 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceParams P)
         if (PERSIST) {
             const uint64_t idleMask = __ballot(cur == kIdle);
             const int nIdle = __popcll(idleMask);
-            if (!exhausted && (nIdle >= kRefillMin || idleMask == ~0ull)) {
-                if (chunkNext == chunkEnd) {
+            if (!exhausted && (nIdle >= refillMin || idleMask == ~0ull)) {
+                // A wave drains the range of the XCD it runs on first, so that (with a sorted
+                // batch) each XCD's private L2 serves one compact region of the scene, and only
+                // then helps with the other ranges.
+                while (chunkNext == chunkEnd && !exhausted) {
+                    const uint32_t range = (homeXcd + rangesDone) & 7u;
+                    const uint32_t rBegin = rangeBegin(P.n, range), rEnd = rangeBegin(P.n, range + 1);
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(P.workCounter, kChunk);
-                    base = __shfl(base, 0);
-                    if (base >= P.n) { exhausted = true; }
-                    else { chunkNext = base; chunkEnd = (P.n - base < kChunk) ? P.n : base + kChunk; }
+                    if (lane == 0) base = atomicAdd(P.workCounter + range * 8, kChunk);
+                    base = __builtin_amdgcn_readfirstlane(base) + rBegin;
+                    if (base >= rEnd) { if (++rangesDone == 8) exhausted = true; }
+                    else { chunkNext = base; chunkEnd = (rEnd - base < kChunk) ? rEnd : base + kChunk; }
                 }
                 if (!exhausted) {
                     const uint32_t avail = chunkEnd - chunkNext;
@@ -164,14 +220,24 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceParams P)
         }
 
         // ------------------------------------------------------------ descend
-        while (__ballot((cur & kLeafBit) == 0) != 0) {
+        for (;;) {
+            const uint64_t inner = __ballot((cur & kLeafBit) == 0);
+            if (inner == 0) break;
+            // leave for the leaf phase once few lanes still descend and some lane waits at a leaf
+            if (__popcll(inner) < nodeMin && __ballot(cur != kIdle && (cur & kLeafBit)) != 0) break;
             if ((cur & kLeafBit) == 0) {
                 const float4* p = P.pairs + (size_t)(cur & 0x1FFFFFFFu) * 4;
                 const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
                 const uint32_t axis = cur >> 29;
                 const float bound = (PRUNE && !ANY) ? tcur : r.tmax;
-                const bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, bound);
-                const bool h1 = slab(q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, r, bound);
+                bool h0, h1;
+                if (__ballot(odd) != 0) {            // rare: some lane's ray can produce NaN plane distances
+                    h0 = slabExact(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, bound);
+                    h1 = slabExact(q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, r, bound);
+                } else {
+                    h0 = slabFast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, bound);
+                    h1 = slabFast(q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, r, bound);
+                }
                 const uint32_t r0 = __float_as_uint(q1.z), r1 = __float_as_uint(q3.z);
                 if (COUNT) cNodes += 2;
                 // src/bvhaccel.cpp:255: left child first iff ray.dir[splitAxis] > 0
@@ -185,14 +251,14 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceParams P)
         }
 
         // ------------------------------------------------------------ leaf
-        if (cur != kIdle) {
+        if (cur != kIdle && (cur & kLeafBit)) {
             const uint32_t slot0 = (cur & 0x7FFFFFFFu) >> 3;
             const uint32_t cnt = cur & 7u;
             bool stop = false;
             if (PRIM == 0) {
                 for (uint32_t i = 0; i < cnt; ++i) {
                     const float4* tp = P.prims + (size_t)(slot0 + i) * 3;
-                    const float4 A = tp[0], B = tp[1], C = tp[2];
+                    const float4 A = tp[0];
                     if (COUNT) ++cPrims;
                     // include/triaccel.h:169-201
                     const int k = __float_as_int(A.w);
@@ -203,6 +269,7 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceParams P)
                     const float nd = 1.0f / (dk + A.x * du + A.y * dv);
                     const float t = (A.z - ok - A.x * ou - A.y * ov) * nd;
                     if (!(tcur > t && t > 0.0001f)) continue;
+                    const float4 B = tp[1], C = tp[2];             // rows b_*, c_* only for a t in range
                     const float phu = ou + t * du;
                     const float phv = ov + t * dv;
                     const float lambda = phu * B.x + phv * B.y + B.z;
@@ -235,10 +302,11 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceParams P)
                     // float(t); among candidates with float(t) == F the winner is the larger of
                     // (lowest index) and (highest index whose double t is still < F).
                     const float f = (float)t;
+                    if (minS >= 0 && f > tcur) continue;
                     const int32_t idx = (int32_t)P.primIndex[slot0 + i];
                     const bool below = t < (double)f;
                     if (minS < 0 || f < tcur) { tcur = f; minS = idx; maxL = below ? idx : -1; }
-                    else if (f == tcur) {
+                    else {
                         minS = (idx < minS) ? idx : minS;
                         if (below && idx > maxL) maxL = idx;
                     }
