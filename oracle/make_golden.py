@@ -34,6 +34,7 @@ def run_reference(verts, tris, sph, rays, shadow_rays):
     out = dict(
         verts=verts, tris=tris, spheres=sph, rays=rays, shadow_rays=shadow_rays,
         nodes=ref.nodes().view(np.uint8), triaccel=ref.triaccel().view(np.uint8),
+        vertex_normals=ref.vertex_normals(),
         hit=h["hit"].astype(np.uint8), t=h["t"], u=h["u"], v=h["v"], prim=h["prim"],
         normal=h["normal"], shading_normal=h["shadingNormal"],
         occluded=ref.intersect_shadow(shadow_rays),

@@ -160,6 +160,17 @@ class Reference:
         self.lib.ref_get_triaccel(self.h, _p(out))
         return out
 
+    def vertex_normals(self):
+        """The per-vertex normals the reference's TriangleMesh constructor generated."""
+        nm = int(self.tris[:, 3].max()) + 1 if len(self.tris) else 0
+        base = np.zeros(nm, np.int32)
+        for m in range(nm):
+            base[m] = self.tris[self.tris[:, 3] == m][:, :3].min()
+        out = np.full((len(self.verts), 3), np.nan, np.float32)
+        self.lib.ref_get_vertex_normals.argtypes = [c_vp, c_vp, c_vp]
+        self.lib.ref_get_vertex_normals(self.h, _p(base), _p(out))
+        return out
+
     def intersect(self, rays, nthreads=8):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
         out = np.zeros(len(rays), REFHIT_DTYPE)

@@ -217,6 +217,22 @@ void ref_get_triaccel(void* h, void* out)
     std::memcpy(out, rs->scene->accel_->triangles_, rs->numTriangles * sizeof(TriAccel));
 }
 
+// Per-vertex normals the reference generated in TriangleMesh's constructor
+// (include/triangle.h:76-111), scattered back to the caller's global vertex numbering
+// (vertexBase[m] = first global vertex of mesh m).  Scene-ingestion data, exported so that
+// fixtures can carry it as INPUT for the hit post-processing check.
+void ref_get_vertex_normals(void* h, const int32_t* vertexBase, float* out)
+{
+    const auto& ms = static_cast<RefScene*>(h)->scene->meshes_;
+    for (size_t m = 0; m < ms.size(); ++m) {
+        const auto& n = ms[m].normals_;
+        for (size_t k = 0; k < n.size(); ++k) {
+            float* o = out + (size_t)(vertexBase[m] + (int32_t)k) * 3;
+            o[0] = n[k].x; o[1] = n[k].y; o[2] = n[k].z;
+        }
+    }
+}
+
 // Scene::intersect (include/scene.h:136) on every ray; the primitive identity,
 // which the reference API does not return, is recovered from the borrowed
 // pointers in RayHitInfo (sphere: areaLight tag; triangle: bsdf -> mesh) and,
