@@ -175,9 +175,31 @@ def g3_edges():
     return run_reference(verts, tris, sph, rays, sh)
 
 
+def g4_trace():
+    """the reference's own trace() (src/renderer.cpp:29-136, 4096 spp,
+    <= 10 bounces, Rng(y*width+x)) on 32 pixels of the 512x512 Cornell frame of BASELINE configs[0]:
+    the pixels it accumulated, and a strided sample of the ray stream it issued (camera rays,
+    secondary rays after BSDF sampling, shadow rays) with the reference's answers for them."""
+    verts, tris, sph = orc.reference_cornell()
+    W = H = 512
+    gx, gy = np.meshgrid(np.arange(8) * 64 + 29, np.arange(4) * 128 + 67, indexing="ij")
+    pixels = np.stack([gx.ravel(), gy.ravel()], -1).astype(np.int32)
+    rgb = orc.reference_trace_cornell(W, H, pixels, mode=0, nthreads=8)
+    rgb1, closest, shadow = orc.reference_trace_cornell(W, H, pixels, mode=1)
+    assert np.array_equal(rgb, rgb1)
+    n_closest, n_shadow = len(closest), len(shadow)
+    closest = closest[:: max(1, len(closest) // 16384)][:16384]
+    shadow = shadow[:: max(1, len(shadow) // 16384)][:16384]
+    d = run_reference(verts, tris, sph, np.ascontiguousarray(closest), np.ascontiguousarray(shadow))
+    d.update(pixels=pixels, rgb=rgb, frame=np.array([W, H], np.int32),
+             stream_counts=np.array([n_closest, n_shadow], np.int64))
+    return d
+
+
 if __name__ == "__main__":
     orc.build_reference()
     os.makedirs(OUT, exist_ok=True)
     save("g1_cornell.npz", g1_cornell())
     save("g2_soup.npz", g2_soup())
     save("g3_edges.npz", g3_edges())
+    save("g4_trace.npz", g4_trace())

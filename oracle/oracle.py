@@ -222,3 +222,44 @@ def reference_uniform_sphere(u12, so=None):
     out = np.zeros((len(u12), 3), np.float32)
     L.ref_uniform_sphere(_p(u12), len(u12), _p(out))
     return out
+
+
+_ENGINE_CLOSEST = ctypes.CFUNCTYPE(ctypes.c_int, c_vp, c_vp, c_sz, c_vp, ctypes.c_uint)
+_ENGINE_ANY = ctypes.CFUNCTYPE(ctypes.c_int, c_vp, c_vp, c_sz, c_vp, ctypes.c_uint)
+
+
+def reference_trace_cornell(width, height, pixels, mode=0, nthreads=8, engine=None, so=None):
+    """The reference's own trace() (src/renderer.cpp:29-136, 4096 spp, <= 10 bounces,
+    Rng(y*width+x)) on the listed (x, y) pixels of a width x height frame of
+    Scene::makeCornellBox with the camera of src/rt.cpp:22-28.
+
+      mode 0 -> rgb [n,3]                                   (the reference's intersection code)
+      mode 1 -> rgb, closest_rays [m,8], shadow_rays [k,8]  (the ray stream trace() issued)
+      mode 2 -> rgb, n_engine_calls; `engine` = (closest_fn_addr, any_fn_addr, accel_handle, flags):
+                every Scene::intersect / intersectShadow of trace() is answered by those C-ABI
+                entry points through the reference's virtual Shape::intersect hook."""
+    L = ctypes.CDLL(so or REF_SO)
+    L.ref_trace_cornell.restype = ctypes.c_long
+    L.ref_trace_cornell.argtypes = [ctypes.c_int, ctypes.c_int, c_vp, c_sz, ctypes.c_int, ctypes.c_int, c_vp,
+                                    ctypes.POINTER(c_vp), ctypes.POINTER(c_sz), ctypes.POINTER(c_vp),
+                                    ctypes.POINTER(c_sz), c_vp, c_vp, c_vp, ctypes.c_uint]
+    L.ref_free.argtypes = [c_vp]
+    pixels = np.ascontiguousarray(pixels, np.int32).reshape(-1, 2)
+    rgb = np.zeros((len(pixels), 3), np.float32)
+    cl, sh = c_vp(), c_vp()
+    ncl, nsh = c_sz(0), c_sz(0)
+    fc, fa, acc, flags = engine if engine is not None else (None, None, None, 0)
+    rc = L.ref_trace_cornell(width, height, _p(pixels), len(pixels), mode, nthreads, _p(rgb),
+                             ctypes.byref(cl), ctypes.byref(ncl), ctypes.byref(sh), ctypes.byref(nsh),
+                             fc, fa, acc, flags)
+    if mode == 1:
+        closest = np.ctypeslib.as_array(ctypes.cast(cl, ctypes.POINTER(ctypes.c_float)), (ncl.value, 8)).copy()
+        shadow = np.ctypeslib.as_array(ctypes.cast(sh, ctypes.POINTER(ctypes.c_float)), (nsh.value, 8)).copy()
+        L.ref_free(cl)
+        L.ref_free(sh)
+        return rgb, closest, shadow
+    if mode == 2:
+        if rc < 0:
+            raise RuntimeError("engine call failed inside trace()")
+        return rgb, int(rc)
+    return rgb

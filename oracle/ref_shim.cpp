@@ -42,6 +42,10 @@
 // this TU *is* the bvhaccel translation unit of the reference build.
 #include "../src/bvhaccel.cpp"
 #undef private
+// The reference's renderer: trace() (src/renderer.cpp:29-136) is driven directly, pixel by
+// pixel, for the caller-harness fixtures.  Renderer::render / TileTask come
+// along and need the reference's scheduler at link time (src/scheduler.cpp, built beside this).
+#include "../src/renderer.cpp"
 
 namespace {
 
@@ -168,6 +172,17 @@ void parallelFor(size_t n, int nthreads, F&& f)
     for (auto& t : th) t.join();
 }
 
+template <class F>
+void parallelFor1(size_t n, int nthreads, F&& f)
+{
+    if (nthreads <= 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
+    std::vector<std::thread> th;
+    std::atomic<size_t> next{0};
+    for (int t = 0; t < nthreads; ++t)
+        th.emplace_back([&]() { for (size_t i; (i = next.fetch_add(1)) < n;) f(i); });
+    for (auto& t : th) t.join();
+}
+
 Ray makeRay(const float* r)
 {
     Ray ray(Vector3f(r[0], r[1], r[2]), Vector3f(r[4], r[5], r[6]));
@@ -176,9 +191,157 @@ Ray makeRay(const float* r)
     return ray;
 }
 
+// ---- caller harness: the reference's own trace() as the driver ------------
+//
+// Scene::intersect and Scene::intersectShadow call every Shape's virtual intersect() before the
+// BVH (include/scene.h:142-144, :176-180).  Two Shape subclasses use that hook, without touching
+// any reference source:
+//   SpyShape    returns "no hit" and records the ray -> the exact ray stream trace() issues
+//   EngineShape forwards the query to an external intersection engine through two C function
+//               pointers (the C-ABI of include/yart_amd.h) and fills RayHitInfo the way the
+//               reference does after a hit (src/bvhaccel.cpp:283-292, include/sphere.h:79-83)
+//               -> the reference's renderer, BSDFs, lights and RNG drive the engine as a drop-in.
+struct RayLog { std::vector<float> closest, shadow; };
+thread_local RayLog* tlsLog = nullptr;
+
+void logRay(const Ray& ray)
+{
+    // trace() builds closest-hit rays with maxT = +inf (include/vector.h:244-249) and shadow rays
+    // with a finite maxT (src/renderer.cpp:101-102): that is how the two kinds are told apart.
+    auto& v = std::isinf(ray.maxT) ? tlsLog->closest : tlsLog->shadow;
+    const float r[8] = { ray.orig.x, ray.orig.y, ray.orig.z, ray.minT, ray.dir.x, ray.dir.y, ray.dir.z, ray.maxT };
+    v.insert(v.end(), r, r + 8);
+}
+
+class SpyShape : public Shape {
+public:
+    bool intersect(const Ray& ray, RayHitInfo* const) const override { if (tlsLog) logRay(ray); return false; }
+    Vector3f sample(float, float, float* pdf) const override { *pdf = 0.0f; return Vector3f(0.0f, 0.0f, 0.0f); }
+    float area() const override { return 0.0f; }
+};
+
+struct EngineHit { float t, u, v; int32_t prim; };          // = YartHit
+typedef int (*EngineClosestFn)(void* accel, const void* rays, size_t n, void* hits, unsigned flags);
+typedef int (*EngineAnyFn)(void* accel, const void* rays, size_t n, uint8_t* occluded, unsigned flags);
+
+class EngineShape : public Shape {
+public:
+    EngineShape(const Scene& geometry, const TriAccel* leafOrder, EngineClosestFn c, EngineAnyFn a, void* accel,
+                unsigned flags)
+        : geometry_(geometry), leafOrder_(leafOrder), closest_(c), any_(a), accel_(accel), flags_(flags) { }
+
+    bool intersect(const Ray& ray, RayHitInfo* const hitInfo) const override
+    {
+        static_assert(sizeof(Ray) == 32, "Ray must be the 32-byte record the engine takes");
+        if (!std::isinf(ray.maxT)) {                        // Scene::intersectShadow
+            uint8_t occ = 0;
+            if (any_(accel_, &ray, 1, &occ, flags_) != 0) { failed = true; return false; }
+            ++numAny;
+            return occ != 0;
+        }
+        EngineHit h;
+        if (closest_(accel_, &ray, 1, &h, flags_) != 0) { failed = true; return false; }
+        ++numClosest;
+        if (h.prim == -1 || !(h.t < hitInfo->t)) return false;
+        hitInfo->t = h.t;
+        hitInfo->u = h.u;
+        hitInfo->v = h.v;
+        if (h.prim >= 0) {                                  // src/bvhaccel.cpp:283-292
+            const TriAccel& ta = leafOrder_[h.prim];
+            const auto& mesh = geometry_.meshes_[ta.meshIdx];
+            hitInfo->normal = mesh.getNormal(ta.triIdx);
+            hitInfo->shadingNormal = mesh.getShadingNormal(ta.triIdx, h.u, h.v);
+            hitInfo->bsdf = mesh.getBsdf();
+            hitInfo->areaLight = nullptr;
+        } else {                                            // include/sphere.h:79-83
+            const auto* sp = static_cast<const Sphere*>(geometry_.shapes_[-(h.prim + 2)].get());
+            hitInfo->normal = normal(ray.orig + ray.dir * hitInfo->t - sp->position_);
+            hitInfo->shadingNormal = hitInfo->normal;
+            hitInfo->bsdf = sp->bsdf_.get();
+            hitInfo->areaLight = sp->getLight();
+        }
+        return true;
+    }
+    Vector3f sample(float, float, float* pdf) const override { *pdf = 0.0f; return Vector3f(0.0f, 0.0f, 0.0f); }
+    float area() const override { return 0.0f; }
+
+    mutable std::atomic<uint64_t> numClosest{0}, numAny{0};
+    mutable std::atomic<bool> failed{false};
+
+private:
+    const Scene& geometry_;
+    const TriAccel* leafOrder_;
+    EngineClosestFn closest_;
+    EngineAnyFn any_;
+    void* accel_;
+    unsigned flags_;
+};
+
+// The camera of src/rt.cpp:22-28 at the given resolution.
+Camera cornellCamera(int width, int height)
+{
+    return Camera(Vector3f(50.0f, 48.0f, 220.0f), normal(Vector3f(0.0f, -0.042612f, -1.0f)), width, height, 0.785398f);
+}
+
 } // namespace
 
 extern "C" {
+
+// trace() (src/renderer.cpp:29-136: 4096 samples per pixel, <= 10 bounces, Rng(y * width + x)) on
+// the listed pixels of a width x height Cornell-box frame (Scene::makeCornellBox, camera of
+// src/rt.cpp:22-28).  rgbOut[i] = the pixel trace() accumulated (Camera::accumulate).
+//   mode 0  the reference's own intersection code
+//   mode 1  as 0, plus the ray stream: every ray handed to Scene::intersect / intersectShadow is
+//           appended to *closestLog / *shadowLog (8 floats each; malloc'ed here, release with
+//           ref_free); pixel order, single thread, so the order is trace()'s own
+//   mode 2  intersection through the engine callbacks (EngineShape); accel / flags are passed on.
+//           Returns the number of engine calls made, or -1 if an engine call failed.
+long ref_trace_cornell(int width, int height, const int32_t* pixels, size_t nPixels, int mode, int nthreads,
+                       float* rgbOut, float** closestLog, size_t* nClosest, float** shadowLog, size_t* nShadow,
+                       EngineClosestFn closestFn, EngineAnyFn anyFn, void* accel, unsigned flags)
+{
+    Scene cornell = Scene::makeCornellBox();
+    Camera camera = cornellCamera(width, height);
+    std::unique_ptr<Scene> scene;
+    std::shared_ptr<EngineShape> engine;
+    std::unique_ptr<BvhAccel> leafOrderSource;
+    if (mode == 2) {
+        // prim ids of the engine index the reference's leaf-ordered TriAccel array
+        leafOrderSource = std::make_unique<BvhAccel>(cornell);
+        engine = std::make_shared<EngineShape>(cornell, leafOrderSource->triangles_, closestFn, anyFn, accel, flags);
+        scene = std::make_unique<Scene>(std::vector<TriangleMesh>(), std::vector<std::shared_ptr<Shape>>{ engine },
+                                        cornell.lights_);
+    } else {
+        auto shapes = cornell.shapes_;
+        if (mode == 1) shapes.insert(shapes.begin(), std::make_shared<SpyShape>());
+        scene = std::make_unique<Scene>(cornell.meshes_, shapes, cornell.lights_);
+    }
+    scene->accel_ = std::make_shared<BvhAccel>(*scene);      // include/scene.h:73 without the TriAccel8 path
+
+    RayLog log;
+    if (mode == 1) nthreads = 1;
+    parallelFor1(nPixels, nthreads, [&](size_t i) {
+        tlsLog = (mode == 1) ? &log : nullptr;
+        trace(*scene, camera, pixels[i * 2 + 0], pixels[i * 2 + 1]);
+        tlsLog = nullptr;
+    });
+    for (size_t i = 0; i < nPixels; ++i) {
+        const RGBColor& c = camera.sensor_.buffer_[(size_t)pixels[i * 2 + 1] * width + pixels[i * 2 + 0]];
+        rgbOut[i * 3 + 0] = c.r; rgbOut[i * 3 + 1] = c.g; rgbOut[i * 3 + 2] = c.b;
+    }
+    if (mode == 1) {
+        *nClosest = log.closest.size() / 8;
+        *nShadow = log.shadow.size() / 8;
+        *closestLog = static_cast<float*>(std::malloc(log.closest.size() * 4 + 4));
+        *shadowLog = static_cast<float*>(std::malloc(log.shadow.size() * 4 + 4));
+        std::memcpy(*closestLog, log.closest.data(), log.closest.size() * 4);
+        std::memcpy(*shadowLog, log.shadow.data(), log.shadow.size() * 4);
+    }
+    if (mode == 2) return engine->failed ? -1 : (long)(engine->numClosest + engine->numAny);
+    return 0;
+}
+
+void ref_free(void* p) { std::free(p); }
 
 void* ref_scene_create(const float* verts, size_t nVerts, const int32_t* tris, size_t nTris,
                        const float* spheres, size_t nSpheres, int genNormals)

@@ -21,7 +21,7 @@ def load_golden(name):
         return {k: z[k] for k in z.files}
 
 
-@pytest.fixture(scope="session", params=["g1_cornell.npz", "g2_soup.npz", "g3_edges.npz"])
+@pytest.fixture(scope="session", params=["g1_cornell.npz", "g2_soup.npz", "g3_edges.npz", "g4_trace.npz"])
 def golden(request):
     d = load_golden(request.param)
     d["name"] = request.param

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -59,6 +60,13 @@ struct YartAccel {
     uint64_t profiledCalls = 0;
     // scheduling knobs of the persistent kernel (YART_REFILL_MIN / YART_NODE_MIN override)
     uint32_t refillMin = 16, nodeMin = 24;
+    // Small host-buffer calls (the one-ray-per-call pattern of the reference's renderer,
+    // src/renderer.cpp:59,104): a pool of { stream, pinned host block the kernels read and
+    // write in place } so that such a call costs launches + one stream synchronise, no
+    // allocation and no copy.  A context is taken for the duration of one call.
+    struct Staging { hipStream_t stream = nullptr; void* host = nullptr; void* dev = nullptr; };
+    std::mutex stagingMutex;
+    std::vector<Staging> stagingFree;
 
     uint32_t* counterSlot()
     {
@@ -272,6 +280,10 @@ void yart_accel_destroy(YartAccel* a)
         (void)hipFree(a->dSphRecs);
         (void)hipFree(a->dSphIndex);
         (void)hipFree(a->dCounters);
+        for (auto& c : a->stagingFree) {
+            (void)hipHostFree(c.host);
+            (void)hipStreamDestroy(c.stream);
+        }
     }
     delete a;
 }
@@ -300,6 +312,48 @@ int yart_intersect_any_counted_dev(YartAccel* accel, const YartRay* d_rays, size
     return run(accel, Launch{ true, true, d_rays, n, nullptr, d_occluded, d_counts, flags, static_cast<hipStream_t>(stream) });
 }
 
+// Batches of up to kStagingRays rays go through a pooled pinned block (see YartAccel::Staging).
+constexpr size_t kStagingRays = 4096;
+constexpr size_t kStagingBytes = kStagingRays * (sizeof(YartRay) + sizeof(YartHit));
+
+static int smallHostCall(YartAccel* accel, const YartRay* rays, size_t n, YartHit* hits, uint8_t* occluded, unsigned flags)
+{
+    YartAccel::Staging c;
+    {
+        std::lock_guard<std::mutex> lock(accel->stagingMutex);
+        if (!accel->stagingFree.empty()) { c = accel->stagingFree.back(); accel->stagingFree.pop_back(); }
+    }
+    if (!c.host) {
+        hipError_t e = hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return failHip(e, "hipStreamCreate");
+        e = hipHostMalloc(&c.host, kStagingBytes, hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(&c.dev, c.host, 0);
+        if (e != hipSuccess) {
+            (void)hipHostFree(c.host);
+            (void)hipStreamDestroy(c.stream);
+            return fail(YART_ERR_OUT_OF_MEMORY, std::string("pinned staging block: ") + hipGetErrorString(e));
+        }
+    }
+    std::memcpy(c.host, rays, n * sizeof(YartRay));
+    char* dOut = static_cast<char*>(c.dev) + kStagingRays * sizeof(YartRay);
+    const char* hOut = static_cast<char*>(c.host) + kStagingRays * sizeof(YartRay);
+    // a handful of rays cannot fill persistent workgroups: plain grid, no counter reset
+    const unsigned f = flags | YART_STATIC_LAUNCH;
+    int st = hits ? yart_intersect_closest_dev(accel, static_cast<YartRay*>(c.dev), n, reinterpret_cast<YartHit*>(dOut), f, c.stream)
+                  : yart_intersect_any_dev(accel, static_cast<YartRay*>(c.dev), n, reinterpret_cast<uint8_t*>(dOut), f, c.stream);
+    if (st == YART_OK) {
+        const hipError_t e = hipStreamSynchronize(c.stream);
+        if (e != hipSuccess) st = failHip(e, "hipStreamSynchronize");
+    }
+    if (st == YART_OK) {
+        if (hits) std::memcpy(hits, hOut, n * sizeof(YartHit));
+        else std::memcpy(occluded, hOut, n);
+    }
+    std::lock_guard<std::mutex> lock(accel->stagingMutex);
+    accel->stagingFree.push_back(c);
+    return st;
+}
+
 static int hostCall(YartAccel* accel, const YartRay* rays, size_t n, YartHit* hits, uint8_t* occluded, unsigned flags)
 {
     if (!accel) return fail(YART_ERR_INVALID_ARGUMENT, "null accel");
@@ -307,6 +361,7 @@ static int hostCall(YartAccel* accel, const YartRay* rays, size_t n, YartHit* hi
     if (!rays || (!hits && !occluded)) return fail(YART_ERR_INVALID_ARGUMENT, "null ray / result pointer");
     DeviceGuard guard(accel->device);
     if (!guard.ok) return fail(YART_ERR_NO_DEVICE, "hipSetDevice failed");
+    if (n <= kStagingRays) return smallHostCall(accel, rays, n, hits, occluded, flags);
     void* dRays = nullptr;
     void* dOut = nullptr;
     const size_t outBytes = hits ? n * sizeof(YartHit) : n;
