@@ -87,7 +87,16 @@ enum yart_flags {
     YART_STATIC_LAUNCH  = 1u << 1,
     /* Sort the batch by a Morton key of origin + direction octant before
      * traversal (results are written back in the caller's order). */
-    YART_SORT_RAYS      = 1u << 2
+    YART_SORT_RAYS      = 1u << 2,
+    /* Distance-pruned traversal of the REFERENCE's binary tree (sphere-tree pass, then the
+     * triangle tree, like include/scene.h:142-146) instead of the engine's own 4-wide
+     * triangle+sphere tree.  Same results as the default up to exact-t ties; slower. */
+    YART_REFERENCE_TREE = 1u << 3,
+    /* Caller's promise that every ray of the batch has finite origin, finite non-zero
+     * 1/dir, minT == 0 and a maxT that is not NaN (what the reference's Ray constructor and
+     * renderer produce, include/vector.h:244-249): skips the fix-up launches that answer any
+     * other ray on the reference's tree. */
+    YART_RAYS_REGULAR   = 1u << 4
 };
 
 /* ---- accel lifetime -------------------------------------------------- */
@@ -131,9 +140,10 @@ int yart_intersect_any_dev(YartAccel* accel, const YartRay* d_rays, size_t n,
                            uint8_t* d_occluded, unsigned flags, void* stream);
 
 /* As above and additionally writes, per ray, FOUR uint32 fetch counters:
- *   [0] 32-byte node records fetched from the triangle tree
+ *   [0] 32-byte node (child) records fetched: four per 128-byte node of the default 4-wide
+ *       tree; with YART_REFERENCE_TREE / _RULE two per 64-byte pair of the triangle tree
  *   [1] 48-byte triangle records tested
- *   [2] 32-byte node records fetched from the sphere tree
+ *   [2] 32-byte node records fetched from the separate sphere tree (reference-tree path only)
  *   [3] 16-byte sphere records tested
  * -- the terms of the algorithmic bytes per ray.  Diagnostic; slower. */
 int yart_intersect_closest_counted_dev(YartAccel* accel, const YartRay* d_rays, size_t n,
@@ -162,6 +172,13 @@ size_t yart_accel_num_triangles(const YartAccel* accel);
 size_t yart_accel_num_spheres(const YartAccel* accel);
 int yart_accel_get_nodes(const YartAccel* accel, YartBvhNode* out);
 int yart_accel_get_triaccel(const YartAccel* accel, YartTriAccel* out);
+/* The engine's own 4-wide tree (no counterpart in the reference): node count (128 bytes
+ * each), 16-byte leaf rows, depth, and a dump of both arrays (layout: yart_amd/csrc/wide_build.h)
+ * for the CPU-side cross-check of the traversal counters. */
+size_t yart_accel_num_wide_nodes(const YartAccel* accel);
+size_t yart_accel_num_wide_rows(const YartAccel* accel);
+int yart_accel_wide_depth(const YartAccel* accel);
+int yart_accel_get_wide(const YartAccel* accel, void* nodes_out, void* rows_out);
 /* Depth of the triangle tree (root = 1) and bytes resident in HBM. */
 int yart_accel_depth(const YartAccel* accel);
 size_t yart_accel_device_bytes(const YartAccel* accel);
@@ -175,8 +192,10 @@ int yart_build_host(const float* verts, size_t n_verts,
 
 /* Per-kernel timing (no counterpart in the reference, which only has a wall-clock
  * Timer around the whole render, include/timer.h:6-26).  While enabled, every
- * intersect call brackets its sort, sphere-tree and triangle-tree launches with HIP
- * events on the caller's stream; yart_accel_profile_read synchronises those events,
+ * intersect call brackets its launches with HIP events on the caller's stream, in three
+ * groups: ms_sort (coherence sort), ms_triangles (the MAIN traversal kernel: the 4-wide tree
+ * kernel, or the triangle-tree pass with YART_REFERENCE_TREE / _RULE) and ms_spheres (the other
+ * passes: sphere-tree pass of the reference-tree path, fix-up launches of the default path); yart_accel_profile_read synchronises those events,
  * adds their durations (milliseconds) and launch counts to the outputs and clears
  * the list.  Not thread-safe; diagnostic. */
 int yart_accel_profile_enable(YartAccel* accel, int enable);

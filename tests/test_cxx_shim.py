@@ -72,4 +72,7 @@ def test_shim_reproduces_reference_hitinfo(tmp_path, golden, rule):
         assert np.array_equal(bits(out[hit, 4:7]), bits(golden["normal"][hit]))
         assert np.array_equal(bits(out[hit, 7:10]), bits(golden["shading_normal"][hit]))
     else:
-        assert (prim == golden["prim"]).mean() >= 0.9999
+        # exact-t ties (g3's box-corner rays) may resolve to another of the tied primitives with the
+        # 4-wide tree: same t bits, see tests/test_gpu_parity.py::assert_within_bar
+        same = (prim == golden["prim"]) | (bits(out[:, 1]) == bits(golden["t"]))
+        assert same.mean() >= 0.9999 and (prim != golden["prim"]).sum() <= 2

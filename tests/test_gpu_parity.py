@@ -34,9 +34,17 @@ def assert_exact(got, want_prim, want_t, want_u, want_v):
     assert np.array_equal(bits(got["v"][hit]), bits(want_v[hit]))
 
 
-def assert_within_bar(got, want_prim, want_t):
+def assert_within_bar(got, want_prim, want_t, exact_ties_ok=False):
+    """exact_ties_ok: a ray whose returned primitive differs but whose t is bit-identical to the
+    reference's (two primitives at exactly the same distance: a box corner, coplanar duplicates)
+    is not counted as a mismatch.  Which of the tied primitives the reference keeps depends on
+    the visiting order of ITS tree (first found wins); the 4-wide tree resolves ties to the lowest
+    leaf slot.  Only the constructed edge-case set (g3) needs this; it is stated in DESIGN.md."""
     assert np.array_equal(got["prim"] != -1, want_prim != -1), "hit/miss differs"
-    same = (got["prim"] == want_prim).mean()
+    same_prim = got["prim"] == want_prim
+    if exact_ties_ok:
+        same_prim = same_prim | (bits(got["t"]) == bits(want_t))
+    same = same_prim.mean()
     assert same >= MIN_SAME_PRIM, same
     m = want_prim != -1
     rel = np.abs(got["t"][m] - want_t[m]) / np.abs(want_t[m])
@@ -63,13 +71,17 @@ def test_closest_reference_rule_is_bit_exact(golden, accel, launch):
 
 
 @pytest.mark.parametrize("launch", LAUNCHES)
-def test_closest_pruned_within_bar(golden, accel, launch):
-    got = api.hits_to_numpy(accel.intersect_closest(dev(golden["rays"]), launch))
-    assert_within_bar(got, golden["prim"], golden["t"])
+@pytest.mark.parametrize("tree", [0, api.YART_REFERENCE_TREE], ids=["wide", "reftree"])
+def test_closest_pruned_within_bar(golden, accel, launch, tree):
+    got = api.hits_to_numpy(accel.intersect_closest(dev(golden["rays"]), launch | tree))
+    ties = tree == 0 and golden["name"] == "g3_edges.npz"
+    assert_within_bar(got, golden["prim"], golden["t"], exact_ties_ok=ties)
+    if ties:        # lowest-slot rule: coplanar duplicates resolve as in the reference; only corner ties remain
+        assert (got["prim"] != golden["prim"]).sum() <= 2
 
 
 @pytest.mark.parametrize("launch", LAUNCHES)
-@pytest.mark.parametrize("rule", [0, api.YART_REFERENCE_RULE])
+@pytest.mark.parametrize("rule", [0, api.YART_REFERENCE_TREE, api.YART_REFERENCE_RULE], ids=["wide", "reftree", "refrule"])
 def test_any_hit_matches_reference(golden, accel, launch, rule):
     occ = accel.intersect_any(dev(golden["shadow_rays"]), rule | launch).cpu().numpy()
     assert np.array_equal(occ, golden["occluded"])
@@ -90,7 +102,7 @@ def test_fetch_counters_match_cpu_counting_oracle(golden, accel):
     _, want = o.intersect(golden["rays"], mode=1, counts=True)
     rays = dev(golden["rays"])
     counts = torch.zeros((len(golden["rays"]), 4), dtype=torch.int32, device="cuda")
-    hits = api.hits_to_numpy(accel.intersect_closest(rays, 0, counts=counts))
+    hits = api.hits_to_numpy(accel.intersect_closest(rays, api.YART_REFERENCE_TREE, counts=counts))
     got = counts.cpu().numpy().astype(np.uint32)
     assert_within_bar(hits, golden["prim"], golden["t"])
     assert np.array_equal(got[:, 0], want[:, 0])           # triangle-tree node records fetched
@@ -98,7 +110,7 @@ def test_fetch_counters_match_cpu_counting_oracle(golden, accel):
     assert (got[:, 3] <= want[:, 3]).all()                 # sphere tree never tests more than the linear loop
     _, want_any = o.intersect_shadow(golden["shadow_rays"], mode=1, counts=True)
     counts.zero_()
-    accel.intersect_any(dev(golden["shadow_rays"]), 0, counts=counts)
+    accel.intersect_any(dev(golden["shadow_rays"]), api.YART_REFERENCE_TREE, counts=counts)
     got_any = counts.cpu().numpy().astype(np.uint32)
     assert np.array_equal(got_any[:, 1], want_any[:, 1])
 
@@ -149,7 +161,7 @@ def test_seeded_soup_against_oracle(n_tris, n_sph, s, n_rays):
     want_occ = o.intersect_shadow(shadow, mode=0, nthreads=16)
     exact = api.hits_to_numpy(a.intersect_closest(dev(rays), api.YART_REFERENCE_RULE))
     assert_exact(exact, want["prim"], want["t"], want["u"], want["v"])
-    for launch in (0, api.YART_SORT_RAYS):
+    for launch in (0, api.YART_SORT_RAYS, api.YART_SORT_RAYS | api.YART_REFERENCE_TREE):
         fast = api.hits_to_numpy(a.intersect_closest(dev(rays), launch))
         assert_within_bar(fast, want["prim"], want["t"])
         assert np.array_equal(a.intersect_any(dev(shadow), launch).cpu().numpy(), want_occ)

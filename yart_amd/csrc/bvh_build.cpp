@@ -250,6 +250,7 @@ int buildTriangleBvh(const float* verts, size_t nVerts, const int32_t* tris, siz
     out.depth = t.depth;
     out.nodes.assign(nNodes, YartBvhNode{});
     out.triaccel.assign(nTris, YartTriAccel{});
+    out.slotOfInput.assign(nTris, 0);
     for (size_t i = 0; i < nNodes; ++i) {
         YartBvhNode& n = out.nodes[i];
         std::memcpy(n.bounds_min, t.box[i].lo, 12);
@@ -260,6 +261,7 @@ int buildTriangleBvh(const float* verts, size_t nVerts, const int32_t* tris, siz
             n.num_triangles = static_cast<uint8_t>(t.end[i] - t.begin[i]);
             for (uint32_t j = t.begin[i]; j < t.end[i]; ++j) {      // src/bvhaccel.cpp:354-360
                 const int32_t* tr = tris + static_cast<size_t>(prims[j].id) * 5;
+                out.slotOfInput[prims[j].id] = slot[i] + (j - t.begin[i]);
                 projectTriangle(out.triaccel[slot[i] + (j - t.begin[i])],
                                 verts + static_cast<size_t>(tr[0]) * 3,
                                 verts + static_cast<size_t>(tr[1]) * 3,

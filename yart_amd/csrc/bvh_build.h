@@ -54,6 +54,7 @@ inline uint32_t leafRef(uint32_t slot, uint32_t count) { return kLeafBit | (slot
 struct TriangleBvh {
     std::vector<YartBvhNode> nodes;       // reference layout and order
     std::vector<YartTriAccel> triaccel;   // leaf order
+    std::vector<uint32_t> slotOfInput;    // caller's triangle number -> leaf slot (index into triaccel)
     std::vector<DevNodePair> pairs;       // pairs[0] = { root, empty leaf }
     int depth = 0;
 };

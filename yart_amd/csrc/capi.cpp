@@ -16,6 +16,7 @@
 #include "../../include/yart_amd.h"
 #include "bvh_build.h"
 #include "traverse.h"
+#include "wide_build.h"
 
 namespace {
 
@@ -51,6 +52,10 @@ struct YartAccel {
     void* dSphRecs = nullptr;
     void* dSphIndex = nullptr;
     void* dCounters = nullptr;
+    void* dWideNodes = nullptr;       // the engine's own 4-wide triangle+sphere tree (wide_build.h)
+    void* dWideRows = nullptr;
+    bool hasWide = false;
+    yart::WideBvh wide;               // host copy kept for yart_accel_get_wide (parity dumps)
     size_t deviceBytes = 0;
     std::atomic<unsigned> nextCounter{ 0 };
     // per-kernel timing (yart_accel_profile_*): kind 0 = sort, 1 = sphere tree, 2 = triangle tree
@@ -59,7 +64,7 @@ struct YartAccel {
     std::vector<Span> spans;
     uint64_t profiledCalls = 0;
     // scheduling knobs of the persistent kernel (YART_REFILL_MIN / YART_NODE_MIN override)
-    uint32_t refillMin = 16, nodeMin = 24;
+    uint32_t refillMin = 16, nodeMin = 24, wideNodeMin = 24;
     // Small host-buffer calls (the one-ray-per-call pattern of the reference's renderer,
     // src/renderer.cpp:59,104): a pool of { stream, pinned host block the kernels read and
     // write in place } so that such a call costs launches + one stream synchronise, no
@@ -174,7 +179,31 @@ int run(YartAccel* a, const Launch& L)
     P.refillMin = a->refillMin;
     P.nodeMin = a->nodeMin;
     hipError_t e = hipSuccess;
-    if (a->numSpheres > 0) {
+    const bool useWide = a->hasWide && !(L.flags & (YART_REFERENCE_RULE | YART_REFERENCE_TREE));
+    P.deferFlag = nullptr;
+    P.onlyDeferred = 0;
+    bool fixupOnly = false;
+    if (useWide) {
+        yart::WideParams W;
+        std::memset(&W, 0, sizeof W);
+        W.nodes = static_cast<const float4*>(a->dWideNodes);
+        W.rows = static_cast<const float4*>(a->dWideRows);
+        W.rays = P.rays; W.perm = perm; W.n = n;
+        W.hits = P.hits; W.occluded = P.occluded; W.counts = P.counts;
+        W.workCounter = a->counterSlot();
+        W.deferFlag = W.workCounter + 1;
+        W.refillMin = a->refillMin; W.nodeMin = a->wideNodeMin;
+        {
+            ScopedSpan span(a, 2, L.stream);
+            e = yart::launchTraceWide(W, L.any, L.count, persistent, a->numCUs, L.stream);
+        }
+        // rays the wide kernel does not take (!regularRay) are answered on the reference tree
+        P.deferFlag = W.deferFlag;
+        P.onlyDeferred = 1;
+        fixupOnly = true;
+    }
+    const bool skipRefTree = fixupOnly && (L.flags & YART_RAYS_REGULAR);
+    if (e == hipSuccess && !skipRefTree && a->numSpheres > 0) {
         // Scene::intersect / intersectShadow visit the spheres before the triangle tree
         // (include/scene.h:142-146, :176-182); the triangle pass starts from the sphere hit.
         P.pairs = static_cast<const float4*>(a->dSphPairs);
@@ -185,13 +214,13 @@ int run(YartAccel* a, const Launch& L)
         ScopedSpan span(a, 1, L.stream);
         e = yart::launchTrace(P, 1, L.any, prune, L.count, persistent, a->numCUs, L.stream);
     }
-    if (e == hipSuccess) {
+    if (e == hipSuccess && !skipRefTree) {
         P.pairs = static_cast<const float4*>(a->dTriPairs);
         P.prims = static_cast<const float4*>(a->dTriAccel);
         P.primIndex = nullptr;
         P.workCounter = a->counterSlot();
         P.chained = a->numSpheres > 0 ? 1u : 0u;
-        ScopedSpan span(a, 2, L.stream);
+        ScopedSpan span(a, fixupOnly ? 1 : 2, L.stream);
         e = yart::launchTrace(P, 0, L.any, prune, L.count, persistent, a->numCUs, L.stream);
     }
     if (sortWs) (void)hipFreeAsync(sortWs, L.stream);
@@ -223,10 +252,21 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
     if (a->refillMin > 64) a->refillMin = 64;
     if (a->nodeMin < 1) a->nodeMin = 1;
     if (a->nodeMin > 64) a->nodeMin = 64;
+    a->wideNodeMin = a->nodeMin;
+    if (const char* v = std::getenv("YART_WIDE_NODE_MIN")) a->wideNodeMin = static_cast<uint32_t>(std::atoi(v));
+    if (a->wideNodeMin < 1) a->wideNodeMin = 1;
+    if (a->wideNodeMin > 64) a->wideNodeMin = 64;
     std::string err;
     int st = yart::buildTriangleBvh(verts, n_verts, tris, n_tris, a->tri, err);
     yart::SphereBvh sph;
     if (st == YART_OK) st = yart::buildSphereBvh(spheres, n_spheres, sph, err);
+    const char* noWide = std::getenv("YART_NO_WIDE");
+    const bool wantWide = !(noWide && noWide[0] == '1');
+    if (st == YART_OK && wantWide) {
+        int maxLeaf = 4;
+        if (const char* v = std::getenv("YART_WIDE_LEAF")) maxLeaf = std::atoi(v);
+        st = yart::buildWideBvh(verts, n_verts, tris, n_tris, a->tri, spheres, n_spheres, maxLeaf, a->wide, err);
+    }
     if (st != YART_OK) { delete a; return fail(st, err); }
     a->numTriPairs = a->tri.pairs.size();
     a->numSphPairs = sph.pairs.size();
@@ -255,6 +295,11 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
     if (st == YART_OK) st = upload(&a->dSphPairs, sph.pairs.data(), sph.pairs.size() * sizeof(yart::DevNodePair), a->deviceBytes);
     if (st == YART_OK) st = upload(&a->dSphRecs, sph.records.data(), sph.records.size() * sizeof(float), a->deviceBytes);
     if (st == YART_OK) st = upload(&a->dSphIndex, sph.index.data(), sph.index.size() * sizeof(uint32_t), a->deviceBytes);
+    if (st == YART_OK && wantWide) {
+        st = upload(&a->dWideNodes, a->wide.nodes.data(), a->wide.nodes.size() * sizeof(yart::WideNode), a->deviceBytes);
+        if (st == YART_OK) st = upload(&a->dWideRows, a->wide.rows.data(), a->wide.rows.size() * sizeof(float), a->deviceBytes);
+        a->hasWide = (st == YART_OK);
+    }
     if (st == YART_OK) {
         hipError_t e = hipMalloc(&a->dCounters, 256 * kCounterSlots);
         if (e != hipSuccess) st = fail(YART_ERR_OUT_OF_MEMORY, "hipMalloc(counters) failed");
@@ -280,6 +325,8 @@ void yart_accel_destroy(YartAccel* a)
         (void)hipFree(a->dSphRecs);
         (void)hipFree(a->dSphIndex);
         (void)hipFree(a->dCounters);
+        (void)hipFree(a->dWideNodes);
+        (void)hipFree(a->dWideRows);
         for (auto& c : a->stagingFree) {
             (void)hipHostFree(c.host);
             (void)hipStreamDestroy(c.stream);
@@ -337,8 +384,12 @@ static int smallHostCall(YartAccel* accel, const YartRay* rays, size_t n, YartHi
     std::memcpy(c.host, rays, n * sizeof(YartRay));
     char* dOut = static_cast<char*>(c.dev) + kStagingRays * sizeof(YartRay);
     const char* hOut = static_cast<char*>(c.host) + kStagingRays * sizeof(YartRay);
-    // a handful of rays cannot fill persistent workgroups: plain grid, no counter reset
-    const unsigned f = flags | YART_STATIC_LAUNCH;
+    // a handful of rays cannot fill persistent workgroups: plain grid.  The rays are in host
+    // memory here, so whether any of them needs the fix-up launches is known up front.
+    bool regular = true;
+    for (size_t i = 0; i < n && regular; ++i)
+        regular = yart::regularRay(rays[i].ox, rays[i].oy, rays[i].oz, rays[i].tmin, rays[i].dx, rays[i].dy, rays[i].dz, rays[i].tmax);
+    const unsigned f = flags | YART_STATIC_LAUNCH | (regular ? YART_RAYS_REGULAR : YART_REFERENCE_TREE);
     int st = hits ? yart_intersect_closest_dev(accel, static_cast<YartRay*>(c.dev), n, reinterpret_cast<YartHit*>(dOut), f, c.stream)
                   : yart_intersect_any_dev(accel, static_cast<YartRay*>(c.dev), n, reinterpret_cast<uint8_t*>(dOut), f, c.stream);
     if (st == YART_OK) {
@@ -412,6 +463,18 @@ int yart_accel_get_triaccel(const YartAccel* a, YartTriAccel* out)
 {
     if (!a || !out) return fail(YART_ERR_INVALID_ARGUMENT, "null argument");
     std::memcpy(out, a->tri.triaccel.data(), a->tri.triaccel.size() * sizeof(YartTriAccel));
+    return YART_OK;
+}
+
+size_t yart_accel_num_wide_nodes(const YartAccel* a) { return a ? a->wide.nodes.size() : 0; }
+size_t yart_accel_num_wide_rows(const YartAccel* a) { return a ? a->wide.rows.size() / 4 : 0; }
+int yart_accel_wide_depth(const YartAccel* a) { return a ? a->wide.depth : 0; }
+
+int yart_accel_get_wide(const YartAccel* a, void* nodes_out, void* rows_out)
+{
+    if (!a) return fail(YART_ERR_INVALID_ARGUMENT, "null argument");
+    if (nodes_out) std::memcpy(nodes_out, a->wide.nodes.data(), a->wide.nodes.size() * sizeof(yart::WideNode));
+    if (rows_out) std::memcpy(rows_out, a->wide.rows.data(), a->wide.rows.size() * sizeof(float));
     return YART_OK;
 }
 

@@ -21,7 +21,43 @@ struct TraceParams {
     uint32_t chained;           // 1: triangle pass running after the sphere pass (hits/occluded/counts hold its results)
     uint32_t refillMin;         // persistent launch: refill a wave once this many lanes are idle
     uint32_t nodeMin;           // leave the descend loop when fewer lanes than this are at interior nodes
+    const uint32_t* deferFlag;  // fix-up launch after the wide kernel: *deferFlag != 0 iff it left rays behind
+    uint32_t onlyDeferred;      // 1: trace only the rays the wide kernel deferred (!regularRay)
 };
+
+// The wide-tree kernel (traverse_wide.hip) handles "regular" rays: finite origin, finite non-zero
+// 1/dir, minT == 0 (what the reference's Ray constructor sets, include/vector.h:244-249) and a maxT
+// that is not NaN.  For anything else the reference's result depends on how ITS tree's boxes treat
+// NaN plane distances and minT (include/bbox.h:30-50), so those rays are deferred to the kernels
+// that walk the reference's own tree.  One predicate, used by both sides.
+__host__ __device__ inline bool regularRay(float ox, float oy, float oz, float tmin,
+                                           float dx, float dy, float dz, float tmax)
+{
+    const float inf = __builtin_inff();
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    return (ix != 0.0f) && (__builtin_fabsf(ix) < inf) && (iy != 0.0f) && (__builtin_fabsf(iy) < inf) &&
+           (iz != 0.0f) && (__builtin_fabsf(iz) < inf) &&
+           (__builtin_fabsf(ox) < inf) && (__builtin_fabsf(oy) < inf) && (__builtin_fabsf(oz) < inf) &&
+           (tmin == 0.0f) && (tmax == tmax);
+}
+
+struct WideParams {
+    const float4* nodes;        // WideNode array viewed as 8 x float4 per node
+    const float4* rows;         // leaf blocks, 16-byte rows (wide_build.h)
+    const float4* rays;
+    const uint32_t* perm;
+    uint32_t n;
+    float4* hits;
+    uint8_t* occluded;
+    uint32_t* counts;
+    uint32_t* workCounter;      // 256-byte slot zeroed by the launcher: counters at words 0, 8, .. 56
+    uint32_t* deferFlag;        // word 1 of the same slot: set when a ray was left for the fix-up launch
+    uint32_t refillMin;
+    uint32_t nodeMin;
+};
+
+hipError_t launchTraceWide(const WideParams& P, bool any, bool count, bool persistent, int numCUs,
+                           hipStream_t stream);
 
 // prim: 0 = triangle tree, 1 = sphere tree.
 hipError_t launchTrace(const TraceParams& P, int prim, bool any, bool prune, bool count,

@@ -141,6 +141,7 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceParams P)
     uint32_t rangesDone = 0;
     const int refillMin = (int)P.refillMin;
     const int nodeMin = (int)P.nodeMin;
+    if (P.onlyDeferred && *P.deferFlag == 0) return;     // uniform: nothing was deferred
 
     auto push = [&](uint32_t v) {
         if (sp < kLdsStack) ldsStack[sp * kBlock + tid] = v;
@@ -160,6 +161,10 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceParams P)
         r.ox = a.x; r.oy = a.y; r.oz = a.z; r.tmin = a.w;
         r.dx = b.x; r.dy = b.y; r.dz = b.z; r.tmax = b.w;
         r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
+        if (P.onlyDeferred && regularRay(r.ox, r.oy, r.oz, r.tmin, r.dx, r.dy, r.dz, r.tmax)) {
+            live = false; cur = kIdle; sp = 0;           // the wide kernel has answered this ray
+            return;
+        }
         // The reference's sphere loop never looks at ray.minT (include/sphere.h:63-97 accepts
         // any t in (1e-4, current t)); only its triangle BVH culls by it (include/bbox.h:32,49).
         if (PRIM == 1) r.tmin = 0.0f;

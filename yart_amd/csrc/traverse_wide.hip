@@ -1,0 +1,341 @@
+// traverse_wide.hip -- the default closest-hit / any-hit kernel: one pass over the engine's own
+// 4-wide BVH of triangles AND spheres (wide_build.h), distance-pruned by the best hit of either kind.
+//
+// Why this shape (measured on MI355X, tools/calib_gather.hip + profiles/): a one-ray-per-lane
+// traversal is bound by how many scattered cache-line requests the memory system retires
+// (~165 G/s from L2, ~50 G/s beyond it) and beyond L2 a 128-byte aligned record costs what a
+// 16-byte one does.  So: one 128-byte node = four child boxes per dependent fetch instead of two,
+// half the levels; leaf blocks 64-byte aligned with the rows every primitive's first rejection
+// needs packed first (four triangle plane rows = one line); spheres in the same tree, so neither
+// kind is traversed beyond the other's hit (the reference's order -- all spheres, then the
+// triangle tree, include/scene.h:142-146 -- cannot prune the sphere loop at all).
+//
+// Semantics reproduced (per ray, independent of visiting order):
+//   triangles  include/triaccel.h:169-201 on the reference's TriAccel bits; accepted iff
+//              1e-4 < t < min(best triangle t, sphere t)         (strict, as `info->t > t`)
+//   spheres    include/sphere.h:63-97 in fp64; the sequential "accept iff t < (double)current float t"
+//              scan over Scene::shapes_ is reproduced by the order-independent rule of traverse.hip
+//   result     the triangle iff its t is strictly below the sphere's float t, else the sphere
+//              (include/scene.h:142-167: spheres first, triangles must be strictly closer)
+// Exact-t ties between two different triangles go to the lower leaf slot (what the reference's
+// in-leaf order gives for coplanar duplicates; ties across ITS leaves depend on its visiting order
+// and are not reproducible with another tree: see DESIGN.md, parity bar).
+//
+// Rays that are not regularRay() (traverse.h) are left to the fix-up launch on the reference tree.
+// Built with -ffp-contract=off: every tested expression rounds as the reference's C++ does.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "traverse.h"
+#include "wide_build.h"
+
+namespace yart {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kLdsStack = 16;
+constexpr int kOvfStack = kWideStack - kLdsStack;
+constexpr uint32_t kChunk = 256;
+constexpr uint32_t kIdle = kWideNone;
+
+__device__ __forceinline__ uint32_t rangeBegin(uint32_t n, uint32_t i)
+{
+    if (i >= 8) return n;
+    const uint32_t chunks = (n + kChunk - 1) / kChunk;
+    const uint32_t b = (uint32_t)(((uint64_t)chunks * i) / 8) * kChunk;
+    return b < n ? b : n;
+}
+
+__device__ __forceinline__ float sel3(int i, float a, float b, float c)
+{
+    return (i == 0) ? a : ((i == 1) ? b : c);
+}
+
+struct WRay {
+    float ox, oy, oz, dx, dy, dz, ix, iy, iz, tmax;
+};
+
+// Slab test of one child record against [0, bound] (minT is 0 for every ray this kernel takes);
+// same products and roundings as include/bbox.h:30-50, min/max form (no NaN can occur for a
+// regular ray and a finite box).  Returns the entry distance through tNear.
+__device__ __forceinline__ bool slab(const float4& a, const float4& b, const WRay& r, float bound, float& tNear)
+{
+    const float ax = (a.x - r.ox) * r.ix, bx = (a.w - r.ox) * r.ix;
+    const float ay = (a.y - r.oy) * r.iy, by = (b.x - r.oy) * r.iy;
+    const float az = (a.z - r.oz) * r.iz, bz = (b.y - r.oz) * r.iz;
+    tNear = fmaxf(fmaxf(0.0f, fminf(ax, bx)), fmaxf(fminf(ay, by), fminf(az, bz)));
+    const float tFar = fminf(fminf(bound, fmaxf(ax, bx)), fminf(fmaxf(ay, by), fmaxf(az, bz)));
+    return !(tFar < tNear) && (tFar > 0.0f) && (tNear < r.tmax);
+}
+
+#define YART_CSWAP(i, j)                                                   \
+    {                                                                      \
+        const bool s_ = tn[j] < tn[i];                                     \
+        const float tf_ = s_ ? tn[j] : tn[i], tg_ = s_ ? tn[i] : tn[j];    \
+        const uint32_t rf_ = s_ ? rf[j] : rf[i], rg_ = s_ ? rf[i] : rf[j]; \
+        tn[i] = tf_; tn[j] = tg_; rf[i] = rf_; rf[j] = rg_;                \
+    }
+
+template <bool ANY, bool COUNT, bool PERSIST>
+__global__ void __launch_bounds__(kBlock) traceWide(WideParams P)
+{
+    __shared__ uint32_t ldsStack[kLdsStack * kBlock];
+    uint32_t ovf[kOvfStack];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint64_t laneBit = 1ull << lane;
+
+    WRay r;
+    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = r.tmax = 0.0f;
+    uint32_t cur = kIdle;
+    int sp = 0;
+    bool live = false;
+    uint32_t rayId = 0;
+    float tTri = 0.0f, hu = 0.0f, hv = 0.0f;      // best triangle
+    int32_t primTri = -1;
+    float F = 0.0f;                                // best sphere: float t, candidates bookkeeping
+    int32_t minS = -1, maxL = -1;
+    uint32_t occ = 0;
+    uint32_t cNodes = 0, cTri = 0, cSph = 0;
+
+    uint32_t chunkNext = 0, chunkEnd = 0;
+    bool exhausted = false;
+    bool firstPass = true;
+    const uint32_t homeXcd = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;   // HW_REG_XCC_ID
+    uint32_t rangesDone = 0;
+    const int refillMin = (int)P.refillMin;
+    const int nodeMin = (int)P.nodeMin;
+
+    auto push = [&](uint32_t v) {
+        if (sp < kLdsStack) ldsStack[sp * kBlock + tid] = v;
+        else ovf[sp - kLdsStack] = v;
+        ++sp;
+    };
+    auto pop = [&]() -> uint32_t {
+        if (sp == 0) return kIdle;
+        --sp;
+        return (sp < kLdsStack) ? ldsStack[sp * kBlock + tid] : ovf[sp - kLdsStack];
+    };
+
+    auto startRay = [&](uint32_t slot) {
+        rayId = P.perm ? P.perm[slot] : slot;
+        const float4 a = P.rays[(size_t)rayId * 2 + 0];
+        const float4 b = P.rays[(size_t)rayId * 2 + 1];
+        if (!regularRay(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w)) {
+            *P.deferFlag = 1u;                     // answered by the fix-up launch on the reference tree
+            return;
+        }
+        r.ox = a.x; r.oy = a.y; r.oz = a.z;
+        r.dx = b.x; r.dy = b.y; r.dz = b.z; r.tmax = b.w;
+        r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
+        tTri = r.tmax; hu = 0.0f; hv = 0.0f; primTri = -1;
+        F = __builtin_inff(); minS = -1; maxL = -1; occ = 0;
+        cNodes = 0; cTri = 0; cSph = 0;
+        sp = 0;
+        live = true;
+        cur = 0u;                                  // root node
+    };
+
+    for (;;) {
+        // ------------------------------------------------------------ fetch work
+        if (PERSIST) {
+            const uint64_t idleMask = __ballot(cur == kIdle);
+            const int nIdle = __popcll(idleMask);
+            if (!exhausted && (nIdle >= refillMin || idleMask == ~0ull)) {
+                while (chunkNext == chunkEnd && !exhausted) {
+                    const uint32_t range = (homeXcd + rangesDone) & 7u;
+                    const uint32_t rBegin = rangeBegin(P.n, range), rEnd = rangeBegin(P.n, range + 1);
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(P.workCounter + range * 8, kChunk);
+                    base = __builtin_amdgcn_readfirstlane(base) + rBegin;
+                    if (base >= rEnd) { if (++rangesDone == 8) exhausted = true; }
+                    else { chunkNext = base; chunkEnd = (rEnd - base < kChunk) ? rEnd : base + kChunk; }
+                }
+                if (!exhausted) {
+                    const uint32_t avail = chunkEnd - chunkNext;
+                    const uint32_t rank = __popcll(idleMask & (laneBit - 1));
+                    if (cur == kIdle && rank < avail) startRay(chunkNext + rank);
+                    chunkNext += ((uint32_t)nIdle < avail) ? (uint32_t)nIdle : avail;
+                }
+            }
+            if (__ballot(cur != kIdle) == 0) {
+                if (exhausted) break;
+                continue;
+            }
+        } else {
+            if (firstPass) {
+                const uint32_t slot = blockIdx.x * kBlock + tid;
+                if (slot < P.n) startRay(slot);
+                firstPass = false;
+            }
+            if (__ballot(cur != kIdle) == 0) break;
+        }
+
+        // ------------------------------------------------------------ descend
+        for (;;) {
+            const uint64_t inner = __ballot((cur & kWideLeafBit) == 0);
+            if (inner == 0) break;
+            if (__popcll(inner) < nodeMin && __ballot(cur != kIdle && (cur & kWideLeafBit)) != 0) break;
+            if ((cur & kWideLeafBit) == 0) {
+                const float4* p = P.nodes + (size_t)cur * 8;
+                const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5], q6 = p[6], q7 = p[7];
+                const float bound = ANY ? r.tmax : fminf(tTri, F);
+                float tn[4];
+                uint32_t rf[4];
+                rf[0] = __float_as_uint(q1.z); rf[1] = __float_as_uint(q3.z);
+                rf[2] = __float_as_uint(q5.z); rf[3] = __float_as_uint(q7.z);
+                bool h[4];
+                h[0] = slab(q0, q1, r, bound, tn[0]) && rf[0] != kWideNone;
+                h[1] = slab(q2, q3, r, bound, tn[1]) && rf[1] != kWideNone;
+                h[2] = slab(q4, q5, r, bound, tn[2]) && rf[2] != kWideNone;
+                h[3] = slab(q6, q7, r, bound, tn[3]) && rf[3] != kWideNone;
+                if (COUNT) cNodes += 4;
+                if (ANY) {
+                    // order is irrelevant for an occlusion query
+                    uint32_t next = kIdle;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (h[c]) { if (next == kIdle) next = rf[c]; else push(rf[c]); }
+                    }
+                    cur = (next == kIdle) ? pop() : next;
+                } else {
+                    // nearest child next, the others pushed far to near
+                    const float big = 3.0e38f;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) tn[c] = h[c] ? fminf(tn[c], big) : __builtin_inff();
+                    const int nHit = (int)h[0] + (int)h[1] + (int)h[2] + (int)h[3];
+                    YART_CSWAP(0, 1) YART_CSWAP(2, 3) YART_CSWAP(0, 2) YART_CSWAP(1, 3) YART_CSWAP(1, 2)
+                    if (nHit > 3) push(rf[3]);
+                    if (nHit > 2) push(rf[2]);
+                    if (nHit > 1) push(rf[1]);
+                    cur = (nHit > 0) ? rf[0] : pop();
+                }
+            }
+        }
+
+        // ------------------------------------------------------------ leaf
+        if (cur != kIdle && (cur & kWideLeafBit)) {
+            const uint32_t cnt = ((cur >> 27) & 7u) + 1u;
+            const float4* blk = P.rows + (size_t)(cur & 0x07FFFFFFu) * 4;
+            bool stop = false;
+            if ((cur & kWideSphereBit) == 0) {
+                for (uint32_t i = 0; i < cnt; ++i) {
+                    const float4 A = blk[i];
+                    if (COUNT) ++cTri;
+                    // include/triaccel.h:169-201
+                    const uint32_t kw = __float_as_uint(A.w);
+                    const int k = (int)(kw & 3u);
+                    const float dk = sel3(k, r.dx, r.dy, r.dz), du = sel3(k, r.dy, r.dz, r.dx),
+                                dv = sel3(k, r.dz, r.dx, r.dy);
+                    const float ok = sel3(k, r.ox, r.oy, r.oz), ou = sel3(k, r.oy, r.oz, r.ox),
+                                ov = sel3(k, r.oz, r.ox, r.oy);
+                    const float nd = 1.0f / (dk + A.x * du + A.y * dv);
+                    const float t = (A.z - ok - A.x * ou - A.y * ov) * nd;
+                    const float bound = ANY ? r.tmax : fminf(tTri, F);
+                    // The reference keeps the FIRST triangle it finds at a given t (`info->t > t` is
+                    // strict); coplanar duplicates sit in one of its leaves in slot order, so the lowest
+                    // slot wins there.  An exact tie therefore goes to the lower slot here, whatever
+                    // order this tree finds them in.
+                    const bool tie = !ANY && t == tTri && (int32_t)(kw >> 2) < primTri;
+                    if (!((bound > t || tie) && t > 0.0001f)) continue;
+                    const float4 B = blk[cnt + i], C = blk[2 * cnt + i];
+                    const float phu = ou + t * du;
+                    const float phv = ov + t * dv;
+                    const float lambda = phu * B.x + phv * B.y + B.z;
+                    if (lambda < 0.0f) continue;
+                    const float mue = phu * C.x + phv * C.y + C.z;
+                    if (mue < 0.0f) continue;
+                    if (lambda + mue > 1.0f) continue;
+                    if (ANY) { occ = 1; stop = true; break; }
+                    tTri = t; hv = lambda; hu = mue;       // include/triaccel.h:194-196
+                    primTri = (int32_t)(kw >> 2);
+                }
+            } else {
+                for (uint32_t i = 0; i < cnt; ++i) {
+                    const float4 S = blk[i];
+                    if (COUNT) ++cSph;
+                    // include/sphere.h:63-97
+                    const float opx = S.x - r.ox, opy = S.y - r.oy, opz = S.z - r.oz;
+                    const double b = (double)(opx * r.dx + opy * r.dy + opz * r.dz);
+                    double det = b * b - (double)(opx * opx + opy * opy + opz * opz) + (double)(S.w * S.w);
+                    if (det < 0) continue;
+                    det = sqrt(det);
+                    const double eps = (double)1e-4f;
+                    double t = b - det;
+                    if (!(t > eps)) t = b + det;
+                    if (!(t > eps && t < (double)r.tmax)) continue;
+                    if (ANY) { occ = 1; stop = true; break; }
+                    const float f = (float)t;
+                    // a sphere whose float t lies beyond the best triangle cannot be the result
+                    // (the triangle is strictly closer); beyond the best sphere neither
+                    if (f > fminf(tTri, F)) continue;
+                    const int32_t idx = (int32_t)reinterpret_cast<const uint32_t*>(blk + cnt)[i];
+                    const bool below = t < (double)f;
+                    if (minS < 0 || f < F) { F = f; minS = idx; maxL = below ? idx : -1; }
+                    else {
+                        minS = (idx < minS) ? idx : minS;
+                        if (below && idx > maxL) maxL = idx;
+                    }
+                }
+            }
+            if (stop) { cur = kIdle; sp = 0; }
+            else cur = pop();
+        }
+
+        // ------------------------------------------------------------ retire
+        if (cur == kIdle && live) {
+            live = false;
+            if (ANY) {
+                P.occluded[rayId] = (uint8_t)occ;
+            } else {
+                // include/scene.h:142-167: spheres first, a triangle replaces the sphere only if strictly closer
+                const bool sphere = (minS >= 0) && !(tTri < F);
+                float t = sphere ? F : tTri;
+                int32_t prim = sphere ? -((minS > maxL ? minS : maxL) + 2) : primTri;
+                if (!(t < r.tmax)) prim = -1;
+                if (sphere || prim == -1) { hu = 0.0f; hv = 0.0f; }
+                P.hits[rayId] = make_float4(t, hu, hv, __int_as_float(prim));
+            }
+            if (COUNT) {
+                uint32_t* c = P.counts + (size_t)rayId * 4;
+                c[0] = cNodes; c[1] = cTri; c[2] = 0; c[3] = cSph;
+            }
+        }
+    }
+}
+
+template <bool ANY, bool COUNT>
+hipError_t launchW(const WideParams& P, bool persistent, int numCUs, hipStream_t stream)
+{
+    if (P.n == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(P.workCounter, 0, 256, stream);      // work counters + defer flag
+    if (e != hipSuccess) return e;
+    if (persistent) {
+        int perCU = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, traceWide<ANY, COUNT, true>, kBlock, 0);
+        if (e != hipSuccess) return e;
+        if (perCU < 1) perCU = 1;
+        if (perCU > 8) perCU = 8;
+        uint32_t grid = (uint32_t)numCUs * (uint32_t)perCU;
+        const uint32_t need = (P.n + kChunk - 1) / kChunk;
+        const uint32_t needBlocks = (need + 3) / 4;
+        if (grid > needBlocks) grid = needBlocks;
+        hipLaunchKernelGGL((traceWide<ANY, COUNT, true>), dim3(grid), dim3(kBlock), 0, stream, P);
+    } else {
+        const uint32_t grid = (P.n + kBlock - 1) / kBlock;
+        hipLaunchKernelGGL((traceWide<ANY, COUNT, false>), dim3(grid), dim3(kBlock), 0, stream, P);
+    }
+    return hipGetLastError();
+}
+
+} // namespace
+
+hipError_t launchTraceWide(const WideParams& P, bool any, bool count, bool persistent, int numCUs,
+                           hipStream_t stream)
+{
+    if (any) return count ? launchW<true, true>(P, persistent, numCUs, stream) : launchW<true, false>(P, persistent, numCUs, stream);
+    return count ? launchW<false, true>(P, persistent, numCUs, stream) : launchW<false, false>(P, persistent, numCUs, stream);
+}
+
+} // namespace yart
