@@ -140,8 +140,8 @@ int yart_intersect_any_dev(YartAccel* accel, const YartRay* d_rays, size_t n,
                            uint8_t* d_occluded, unsigned flags, void* stream);
 
 /* As above and additionally writes, per ray, FOUR uint32 fetch counters:
- *   [0] 32-byte node (child) records fetched: four per 128-byte node of the default 4-wide
- *       tree; with YART_REFERENCE_TREE / _RULE two per 64-byte pair of the triangle tree
+ *   [0] node (child) records fetched: four per 64-byte node of the default 4-wide tree
+ *       (16 bytes each); with YART_REFERENCE_TREE / _RULE two 32-byte records per 64-byte pair of the triangle tree
  *   [1] 48-byte triangle records tested
  *   [2] 32-byte node records fetched from the separate sphere tree (reference-tree path only)
  *   [3] 16-byte sphere records tested
@@ -172,7 +172,7 @@ size_t yart_accel_num_triangles(const YartAccel* accel);
 size_t yart_accel_num_spheres(const YartAccel* accel);
 int yart_accel_get_nodes(const YartAccel* accel, YartBvhNode* out);
 int yart_accel_get_triaccel(const YartAccel* accel, YartTriAccel* out);
-/* The engine's own 4-wide tree (no counterpart in the reference): node count (128 bytes
+/* The engine's own 4-wide tree (no counterpart in the reference): node count (64 bytes
  * each), 16-byte leaf rows, depth, and a dump of both arrays (layout: yart_amd/csrc/wide_build.h)
  * for the CPU-side cross-check of the traversal counters. */
 size_t yart_accel_num_wide_nodes(const YartAccel* accel);

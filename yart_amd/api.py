@@ -179,9 +179,9 @@ class Accel:
         return lib().yart_accel_wide_depth(self._h)
 
     def wide(self):
-        """-> (nodes uint32 [nNodes, 32], rows float32 [nRows, 4]) of the 4-wide tree (wide_build.h)."""
+        """-> (nodes uint32 [nNodes, 16], rows float32 [nRows, 4]) of the 4-wide tree (wide_build.h)."""
         L = lib()
-        nodes = np.zeros((L.yart_accel_num_wide_nodes(self._h), 32), np.uint32)
+        nodes = np.zeros((L.yart_accel_num_wide_nodes(self._h), 16), np.uint32)
         rows = np.zeros((L.yart_accel_num_wide_rows(self._h), 4), np.float32)
         _check(L.yart_accel_get_wide(self._h, _p(nodes), _p(rows)))
         return nodes, rows

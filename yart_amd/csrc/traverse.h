@@ -42,7 +42,7 @@ __host__ __device__ inline bool regularRay(float ox, float oy, float oz, float t
 }
 
 struct WideParams {
-    const float4* nodes;        // WideNode array viewed as 8 x float4 per node
+    const float4* nodes;        // WideNode array viewed as 4 x float4 per node
     const float4* rows;         // leaf blocks, 16-byte rows (wide_build.h)
     const float4* rays;
     const uint32_t* perm;

@@ -2,11 +2,11 @@
 // 4-wide BVH of triangles AND spheres (wide_build.h), distance-pruned by the best hit of either kind.
 //
 // Why this shape (measured on MI355X, tools/calib_gather.hip + profiles/): a one-ray-per-lane
-// traversal is bound by how many scattered cache-line requests the memory system retires
-// (~165 G/s from L2, ~50 G/s beyond it) and beyond L2 a 128-byte aligned record costs what a
-// 16-byte one does.  So: one 128-byte node = four child boxes per dependent fetch instead of two,
-// half the levels; leaf blocks 64-byte aligned with the rows every primitive's first rejection
-// needs packed first (four triangle plane rows = one line); spheres in the same tree, so neither
+// traversal is bound by how many scattered line requests (~165 G/s from L2, ~50 G/s beyond it) and
+// 16-byte lane requests (~1 per clock per CU) it issues, not by their bytes.  So: one 64-byte node
+// = four quantised child boxes per dependent fetch (4 lane requests, 1 line; the binary tree's
+// sibling pair costs the same for two boxes), half the levels; leaf blocks 64-byte aligned with the
+// rows every primitive's first rejection needs packed first; spheres in the same tree, so neither
 // kind is traversed beyond the other's hit (the reference's order -- all spheres, then the
 // triangle tree, include/scene.h:142-146 -- cannot prune the sphere loop at all).
 //
@@ -55,17 +55,27 @@ struct WRay {
     float ox, oy, oz, dx, dy, dz, ix, iy, iz, tmax;
 };
 
-// Slab test of one child record against [0, bound] (minT is 0 for every ray this kernel takes);
-// same products and roundings as include/bbox.h:30-50, min/max form (no NaN can occur for a
-// regular ray and a finite box).  Returns the entry distance through tNear.
-__device__ __forceinline__ bool slab(const float4& a, const float4& b, const WRay& r, float bound, float& tNear)
+// A node's grid seen from the ray: per axis t(q) = A + q * B is the distance to grid plane q.
+struct NodeGrid {
+    float Ax, Bx, Ay, By, Az, Bz;
+    uint32_t lx, ly, lz, hx, hy, hz;               // byte c of each = plane of child c
+};
+
+// Slab test of child C against [0, bound] (minT is 0 for every ray this kernel takes).  The boxes are
+// the engine's own (quantised, conservative), so the arithmetic is free to use fma; the primitive
+// tests below are what has to round like the reference.  Returns the entry distance through tNear.
+template <int C>
+__device__ __forceinline__ bool slab(const NodeGrid& g, float tmax, float bound, float& tNear)
 {
-    const float ax = (a.x - r.ox) * r.ix, bx = (a.w - r.ox) * r.ix;
-    const float ay = (a.y - r.oy) * r.iy, by = (b.x - r.oy) * r.iy;
-    const float az = (a.z - r.oz) * r.iz, bz = (b.y - r.oz) * r.iz;
+    const float ax = __builtin_fmaf((float)((g.lx >> (8 * C)) & 255u), g.Bx, g.Ax);
+    const float bx = __builtin_fmaf((float)((g.hx >> (8 * C)) & 255u), g.Bx, g.Ax);
+    const float ay = __builtin_fmaf((float)((g.ly >> (8 * C)) & 255u), g.By, g.Ay);
+    const float by = __builtin_fmaf((float)((g.hy >> (8 * C)) & 255u), g.By, g.Ay);
+    const float az = __builtin_fmaf((float)((g.lz >> (8 * C)) & 255u), g.Bz, g.Az);
+    const float bz = __builtin_fmaf((float)((g.hz >> (8 * C)) & 255u), g.Bz, g.Az);
     tNear = fmaxf(fmaxf(0.0f, fminf(ax, bx)), fmaxf(fminf(ay, by), fminf(az, bz)));
     const float tFar = fminf(fminf(bound, fmaxf(ax, bx)), fminf(fmaxf(ay, by), fmaxf(az, bz)));
-    return !(tFar < tNear) && (tFar > 0.0f) && (tNear < r.tmax);
+    return !(tFar < tNear) && (tFar > 0.0f) && (tNear < tmax);
 }
 
 #define YART_CSWAP(i, j)                                                   \
@@ -178,18 +188,24 @@ __global__ void __launch_bounds__(kBlock) traceWide(WideParams P)
             if (inner == 0) break;
             if (__popcll(inner) < nodeMin && __ballot(cur != kIdle && (cur & kWideLeafBit)) != 0) break;
             if ((cur & kWideLeafBit) == 0) {
-                const float4* p = P.nodes + (size_t)cur * 8;
-                const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5], q6 = p[6], q7 = p[7];
+                const float4* p = P.nodes + (size_t)cur * 4;
+                const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
                 const float bound = ANY ? r.tmax : fminf(tTri, F);
+                NodeGrid g;
+                g.Ax = (q0.x - r.ox) * r.ix; g.Bx = q0.w * r.ix;
+                g.Ay = (q0.y - r.oy) * r.iy; g.By = q1.x * r.iy;
+                g.Az = (q0.z - r.oz) * r.iz; g.Bz = q1.y * r.iz;
+                g.lx = __float_as_uint(q1.z); g.ly = __float_as_uint(q1.w); g.lz = __float_as_uint(q2.x);
+                g.hx = __float_as_uint(q2.y); g.hy = __float_as_uint(q2.z); g.hz = __float_as_uint(q2.w);
                 float tn[4];
                 uint32_t rf[4];
-                rf[0] = __float_as_uint(q1.z); rf[1] = __float_as_uint(q3.z);
-                rf[2] = __float_as_uint(q5.z); rf[3] = __float_as_uint(q7.z);
+                rf[0] = __float_as_uint(q3.x); rf[1] = __float_as_uint(q3.y);
+                rf[2] = __float_as_uint(q3.z); rf[3] = __float_as_uint(q3.w);
                 bool h[4];
-                h[0] = slab(q0, q1, r, bound, tn[0]) && rf[0] != kWideNone;
-                h[1] = slab(q2, q3, r, bound, tn[1]) && rf[1] != kWideNone;
-                h[2] = slab(q4, q5, r, bound, tn[2]) && rf[2] != kWideNone;
-                h[3] = slab(q6, q7, r, bound, tn[3]) && rf[3] != kWideNone;
+                h[0] = slab<0>(g, r.tmax, bound, tn[0]) && rf[0] != kWideNone;
+                h[1] = slab<1>(g, r.tmax, bound, tn[1]) && rf[1] != kWideNone;
+                h[2] = slab<2>(g, r.tmax, bound, tn[2]) && rf[2] != kWideNone;
+                h[3] = slab<3>(g, r.tmax, bound, tn[3]) && rf[3] != kWideNone;
                 if (COUNT) cNodes += 4;
                 if (ANY) {
                     // order is irrelevant for an occlusion query

@@ -1,5 +1,5 @@
 // Host build of the 4-wide triangle+sphere BVH (wide_build.h): binned-SAH binary build on a small
-// thread pool, collapse to four children per node, depth-first emission of 128-byte nodes and
+// thread pool, collapse to four children per node, depth-first emission of 64-byte quantised nodes and
 // 64-byte-aligned leaf blocks.
 #include "wide_build.h"
 
@@ -258,8 +258,8 @@ public:
         }
         if (nodes_[0].count > 0) {                       // the whole scene fits one leaf
             out_.nodes.emplace_back();
-            clear(out_.nodes[0]);
-            setChild(0, 0, nodes_[0].box, leaf(nodes_[0]));
+            const uint32_t ref = leaf(nodes_[0]);
+            setChildren(0, &nodes_[0].box, &ref, 1);
             out_.depth = 1;
             return;
         }
@@ -269,20 +269,54 @@ public:
 private:
     static void clear(WideNode& n)
     {
-        const float inf = std::numeric_limits<float>::infinity();
-        for (auto& c : n.child) {
-            for (int a = 0; a < 3; ++a) { c.lo[a] = inf; c.hi[a] = -inf; }
-            c.ref = kWideNone;
-            c.pad = 0;
+        std::memset(&n, 0, sizeof n);
+        for (int a = 0; a < 3; ++a) {
+            n.scale[a] = 1.0f;
+            for (int c = 0; c < 4; ++c) { n.qlo[a][c] = 255; n.qhi[a][c] = 0; }
         }
+        for (auto& r : n.ref) r = kWideNone;
     }
 
-    void setChild(uint32_t node, int k, const Box& b, uint32_t ref)
+    // Quantise up to four child boxes on the grid of their union.  Containment is decided in double
+    // on the float values the kernel will read: origin + qlo * scale <= lo and origin + qhi * scale >= hi.
+    void setChildren(uint32_t node, const Box* boxesIn, const uint32_t* refs, int n)
     {
-        WideChild& c = out_.nodes[node].child[k];
-        std::memcpy(c.lo, b.lo, 12);
-        std::memcpy(c.hi, b.hi, 12);
-        c.ref = ref;
+        WideNode& w = out_.nodes[node];
+        clear(w);
+        Box all, clamped[4];
+        all.reset();
+        for (int i = 0; i < n; ++i) {
+            clamped[i] = boxesIn[i];                    // keep the grid arithmetic finite
+            for (int a = 0; a < 3; ++a) {
+                clamped[i].lo[a] = std::max(clamped[i].lo[a], -8.0e37f);
+                clamped[i].hi[a] = std::min(clamped[i].hi[a], 8.0e37f);
+            }
+            all.grow(clamped[i]);
+        }
+        const Box* boxes = clamped;
+        for (int a = 0; a < 3; ++a) {
+            const float origin = all.lo[a];
+            float scale = (all.hi[a] - all.lo[a]) / 255.0f;
+            if (!(scale > 0.0f) || !(scale < std::numeric_limits<float>::infinity())) scale = 1.0f;   // flat or unbounded axis
+            for (;;) {
+                bool ok = true;
+                for (int i = 0; i < n && ok; ++i) {
+                    const double lo = boxes[i].lo[a], hi = boxes[i].hi[a];
+                    double ql = std::floor((lo - origin) / scale), qh = std::ceil((hi - origin) / scale);
+                    while (ql > 0.0 && origin + ql * static_cast<double>(scale) > lo) ql -= 1.0;
+                    while (origin + qh * static_cast<double>(scale) < hi) qh += 1.0;
+                    if (ql < 0.0) ql = 0.0;
+                    if (qh > 255.0) { ok = false; break; }
+                    w.qlo[a][i] = static_cast<uint8_t>(ql);
+                    w.qhi[a][i] = static_cast<uint8_t>(qh);
+                }
+                if (ok) break;
+                scale = std::nextafter(scale * 1.000001f, std::numeric_limits<float>::infinity());
+            }
+            w.origin[a] = origin;
+            w.scale[a] = scale;
+        }
+        for (int i = 0; i < n; ++i) w.ref[i] = refs[i];
     }
 
     uint32_t emit(uint32_t bnode, int depth)
@@ -305,12 +339,14 @@ private:
         }
         const uint32_t idx = static_cast<uint32_t>(out_.nodes.size());
         out_.nodes.emplace_back();
-        clear(out_.nodes[idx]);
+        Box boxes[4];
+        uint32_t refs[4];
         for (int i = 0; i < n; ++i) {
             const BNode& c = nodes_[kids[i]];
-            const uint32_t ref = (c.count > 0) ? leaf(c) : emit(kids[i], depth + 1);
-            setChild(idx, i, c.box, ref);
+            boxes[i] = c.box;
+            refs[i] = (c.count > 0) ? leaf(c) : emit(kids[i], depth + 1);
         }
+        setChildren(idx, boxes, refs, n);
         return idx;
     }
 

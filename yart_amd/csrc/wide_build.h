@@ -1,9 +1,11 @@
 // The engine's own acceleration structure for the default (distance-pruned) rule: ONE 4-wide
 // BVH over triangles AND spheres, laid out for how MI355X's memory system charges a scattered
-// fetch (measured, tools/calib_gather.hip): beyond L2 a random aligned 128-byte record costs the
-// same as a 64-byte or a 16-byte one (~45-50 G records/s), so a node is one 128-byte line holding
-// four child records, and a leaf is a 64-byte-aligned block whose first rows are everything the
-// first rejection test of each primitive needs.
+// fetch (measured, tools/calib_gather.hip + profiles/): what a one-ray-per-lane traversal pays for is
+// the NUMBER of scattered line requests and 16-byte lane requests it issues (~1 lane request per
+// clock per CU, ~50 G random lines/s beyond L2), not their bytes.  So a node is ONE 64-byte line
+// holding four quantised child boxes (four 16-byte lane requests per visit instead of the sixteen a
+// binary tree with full-precision boxes needs for the same four boxes), and a leaf is a 64-byte
+// aligned block whose first rows are everything the first rejection test of each primitive needs.
 //
 // The reference has no counterpart (its tree is the binary one of src/bvhaccel.cpp, which the
 // library also keeps, bit for bit, for YART_REFERENCE_RULE / YART_REFERENCE_TREE).  A closest hit
@@ -20,17 +22,20 @@
 
 namespace yart {
 
-// 32-byte child record; four of them make a 128-byte node.
-struct WideChild {
-    float lo[3];
-    float hi[3];
-    uint32_t ref;       // see below
-    uint32_t pad;
+// One node = one 64-byte line: four child boxes quantised to 8 bits per plane on the node's own
+// grid (origin + q * scale per axis; lower planes rounded down, upper planes up, so a quantised box
+// always contains the exact one), SoA by plane so a plane of all four children is one dword.
+//   dwords 0-2  origin x, y, z (float)          dwords 3-5   scale x, y, z (float)
+//   dword  6-8  lower planes x, y, z, byte c = child c      dwords 9-11  upper planes x, y, z
+//   dwords 12-15 child refs
+struct alignas(64) WideNode {
+    float origin[3];
+    float scale[3];
+    uint8_t qlo[3][4];
+    uint8_t qhi[3][4];
+    uint32_t ref[4];
 };
-struct alignas(128) WideNode {
-    WideChild child[4];
-};
-static_assert(sizeof(WideNode) == 128, "wide node is one 128-byte line");
+static_assert(sizeof(WideNode) == 64, "wide node is one 64-byte line");
 
 // ref encoding
 //   interior : bit31 = 0, bits30..0 = node index
@@ -51,7 +56,7 @@ constexpr int kWideStack = 64;          // traversal stack entries per ray (16 i
 //   spheres   (count c): c rows   = cx, cy, cz, radius;   then ceil(c/4) rows of uint32 sphere numbers
 //   padded to a multiple of 4 rows.
 struct WideBvh {
-    std::vector<WideNode> nodes;        // nodes[0] = root
+    std::vector<WideNode> nodes;        // nodes[0] = root; 64 bytes each
     std::vector<float> rows;            // 4 floats per row
     int depth = 0;                      // wide levels (root = 1)
     size_t numLeaves = 0;
