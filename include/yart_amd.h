@@ -173,12 +173,13 @@ size_t yart_accel_num_spheres(const YartAccel* accel);
 int yart_accel_get_nodes(const YartAccel* accel, YartBvhNode* out);
 int yart_accel_get_triaccel(const YartAccel* accel, YartTriAccel* out);
 /* The engine's own 4-wide tree (no counterpart in the reference): node count (64 bytes
- * each), 16-byte leaf rows, depth, and a dump of both arrays (layout: yart_amd/csrc/wide_build.h)
- * for the CPU-side cross-check of the traversal counters. */
+ * each), primitives in its leaves, depth, and a dump of its arrays (nodes; 16 bytes per primitive
+ * of first-stage leaf rows; 32 bytes per primitive of second-stage rows -- layout:
+ * yart_amd/csrc/wide_build.h) for the CPU-side cross-check of the traversal counters. */
 size_t yart_accel_num_wide_nodes(const YartAccel* accel);
-size_t yart_accel_num_wide_rows(const YartAccel* accel);
+size_t yart_accel_num_wide_prims(const YartAccel* accel);
 int yart_accel_wide_depth(const YartAccel* accel);
-int yart_accel_get_wide(const YartAccel* accel, void* nodes_out, void* rows_out);
+int yart_accel_get_wide(const YartAccel* accel, void* nodes_out, void* rows_a_out, void* rows_bc_out);
 /* Depth of the triangle tree (root = 1) and bytes resident in HBM. */
 int yart_accel_depth(const YartAccel* accel);
 size_t yart_accel_device_bytes(const YartAccel* accel);

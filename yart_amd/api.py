@@ -36,7 +36,7 @@ EXPORTS = [
     "yart_accel_get_nodes", "yart_accel_get_triaccel", "yart_accel_depth",
     "yart_accel_device_bytes", "yart_build_host", "yart_status_string", "yart_last_error",
     "yart_accel_profile_enable", "yart_accel_profile_read",
-    "yart_accel_num_wide_nodes", "yart_accel_num_wide_rows", "yart_accel_wide_depth", "yart_accel_get_wide",
+    "yart_accel_num_wide_nodes", "yart_accel_num_wide_prims", "yart_accel_wide_depth", "yart_accel_get_wide",
 ]
 
 _vp = ctypes.c_void_p
@@ -67,12 +67,12 @@ def lib():
     for name in ("yart_intersect_closest", "yart_intersect_any"):
         getattr(L, name).argtypes = [_vp, _vp, _sz, _vp, ctypes.c_uint]
     for name in ("yart_accel_num_nodes", "yart_accel_num_triangles", "yart_accel_num_spheres",
-                 "yart_accel_device_bytes", "yart_accel_num_wide_nodes", "yart_accel_num_wide_rows"):
+                 "yart_accel_device_bytes", "yart_accel_num_wide_nodes", "yart_accel_num_wide_prims"):
         getattr(L, name).argtypes = [_vp]
         getattr(L, name).restype = _sz
     L.yart_accel_depth.argtypes = [_vp]
     L.yart_accel_wide_depth.argtypes = [_vp]
-    L.yart_accel_get_wide.argtypes = [_vp, _vp, _vp]
+    L.yart_accel_get_wide.argtypes = [_vp, _vp, _vp, _vp]
     L.yart_accel_get_nodes.argtypes = [_vp, _vp]
     L.yart_accel_get_triaccel.argtypes = [_vp, _vp]
     L.yart_build_host.argtypes = [_vp, _sz, _vp, _sz, _vp, ctypes.POINTER(_sz), _vp]
@@ -182,7 +182,7 @@ class Accel:
         """-> (nodes uint32 [nNodes, 16], rows float32 [nRows, 4]) of the 4-wide tree (wide_build.h)."""
         L = lib()
         nodes = np.zeros((L.yart_accel_num_wide_nodes(self._h), 16), np.uint32)
-        rows = np.zeros((L.yart_accel_num_wide_rows(self._h), 4), np.float32)
+        rows = np.zeros((L.yart_accel_num_wide_prims(self._h), 4), np.float32)
         _check(L.yart_accel_get_wide(self._h, _p(nodes), _p(rows)))
         return nodes, rows
 

@@ -53,7 +53,8 @@ struct YartAccel {
     void* dSphIndex = nullptr;
     void* dCounters = nullptr;
     void* dWideNodes = nullptr;       // the engine's own 4-wide triangle+sphere tree (wide_build.h)
-    void* dWideRows = nullptr;
+    void* dWideRowsA = nullptr;
+    void* dWideRowsBC = nullptr;
     bool hasWide = false;
     yart::WideBvh wide;               // host copy kept for yart_accel_get_wide (parity dumps)
     size_t deviceBytes = 0;
@@ -64,7 +65,9 @@ struct YartAccel {
     std::vector<Span> spans;
     uint64_t profiledCalls = 0;
     // scheduling knobs of the persistent kernel (YART_REFILL_MIN / YART_NODE_MIN override)
-    uint32_t refillMin = 16, nodeMin = 24, wideNodeMin = 24;
+    uint32_t refillMin = 16, nodeMin = 24;                    // reference-tree kernels
+    uint32_t wideRefillMin = 16, wideNodeMin = 40, wideChunk = 64, wideBlocksPerCU = 0;   // wide-tree kernel
+    uint32_t sortOctShift = 0;
     // Small host-buffer calls (the one-ray-per-call pattern of the reference's renderer,
     // src/renderer.cpp:59,104): a pool of { stream, pinned host block the kernels read and
     // write in place } so that such a call costs launches + one stream synchronise, no
@@ -162,7 +165,7 @@ int run(YartAccel* a, const Launch& L)
         perm = reinterpret_cast<uint32_t*>(static_cast<char*>(sortWs) + wsBytes);
         {
             ScopedSpan span(a, 0, L.stream);
-            e = yart::sortRays(reinterpret_cast<const float4*>(L.rays), n, a->sceneLo, a->sceneHi, perm,
+            e = yart::sortRays(reinterpret_cast<const float4*>(L.rays), n, a->sceneLo, a->sceneHi, a->sortOctShift, perm,
                                sortWs, wsBytes, L.stream);
         }
         if (e != hipSuccess) { (void)hipFreeAsync(sortWs, L.stream); return failHip(e, "sortRays"); }
@@ -187,12 +190,13 @@ int run(YartAccel* a, const Launch& L)
         yart::WideParams W;
         std::memset(&W, 0, sizeof W);
         W.nodes = static_cast<const float4*>(a->dWideNodes);
-        W.rows = static_cast<const float4*>(a->dWideRows);
+        W.rowsA = static_cast<const float4*>(a->dWideRowsA);
+        W.rowsBC = static_cast<const float4*>(a->dWideRowsBC);
         W.rays = P.rays; W.perm = perm; W.n = n;
         W.hits = P.hits; W.occluded = P.occluded; W.counts = P.counts;
         W.workCounter = a->counterSlot();
         W.deferFlag = W.workCounter + 1;
-        W.refillMin = a->refillMin; W.nodeMin = a->wideNodeMin;
+        W.refillMin = a->wideRefillMin; W.nodeMin = a->wideNodeMin; W.chunk = a->wideChunk; W.maxBlocksPerCU = a->wideBlocksPerCU;
         {
             ScopedSpan span(a, 2, L.stream);
             e = yart::launchTraceWide(W, L.any, L.count, persistent, a->numCUs, L.stream);
@@ -252,10 +256,18 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
     if (a->refillMin > 64) a->refillMin = 64;
     if (a->nodeMin < 1) a->nodeMin = 1;
     if (a->nodeMin > 64) a->nodeMin = 64;
-    a->wideNodeMin = a->nodeMin;
+    if (const char* v = std::getenv("YART_WIDE_REFILL_MIN")) a->wideRefillMin = static_cast<uint32_t>(std::atoi(v));
+    if (a->wideRefillMin < 1) a->wideRefillMin = 1;
+    if (a->wideRefillMin > 64) a->wideRefillMin = 64;
     if (const char* v = std::getenv("YART_WIDE_NODE_MIN")) a->wideNodeMin = static_cast<uint32_t>(std::atoi(v));
     if (a->wideNodeMin < 1) a->wideNodeMin = 1;
     if (a->wideNodeMin > 64) a->wideNodeMin = 64;
+    if (const char* v = std::getenv("YART_SORT_OCT_SHIFT")) a->sortOctShift = static_cast<uint32_t>(std::atoi(v));
+    if (const char* v = std::getenv("YART_WIDE_BLOCKS_PER_CU")) a->wideBlocksPerCU = static_cast<uint32_t>(std::atoi(v));
+    if (const char* v = std::getenv("YART_WIDE_CHUNK")) a->wideChunk = static_cast<uint32_t>(std::atoi(v));
+    a->wideChunk = (a->wideChunk + 63) / 64 * 64;
+    if (a->wideChunk < 64) a->wideChunk = 64;
+    if (a->wideChunk > 4096) a->wideChunk = 4096;
     std::string err;
     int st = yart::buildTriangleBvh(verts, n_verts, tris, n_tris, a->tri, err);
     yart::SphereBvh sph;
@@ -263,7 +275,8 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
     const char* noWide = std::getenv("YART_NO_WIDE");
     const bool wantWide = !(noWide && noWide[0] == '1');
     if (st == YART_OK && wantWide) {
-        int maxLeaf = 4;
+        int maxLeaf = 1;            // measured best on MI355X (tools/exp_wide.py): the box of a single primitive is a
+                                    // cheaper rejection than its plane row, and rows of different leaves are not tested
         if (const char* v = std::getenv("YART_WIDE_LEAF")) maxLeaf = std::atoi(v);
         st = yart::buildWideBvh(verts, n_verts, tris, n_tris, a->tri, spheres, n_spheres, maxLeaf, a->wide, err);
     }
@@ -297,7 +310,8 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
     if (st == YART_OK) st = upload(&a->dSphIndex, sph.index.data(), sph.index.size() * sizeof(uint32_t), a->deviceBytes);
     if (st == YART_OK && wantWide) {
         st = upload(&a->dWideNodes, a->wide.nodes.data(), a->wide.nodes.size() * sizeof(yart::WideNode), a->deviceBytes);
-        if (st == YART_OK) st = upload(&a->dWideRows, a->wide.rows.data(), a->wide.rows.size() * sizeof(float), a->deviceBytes);
+        if (st == YART_OK) st = upload(&a->dWideRowsA, a->wide.rowsA.data(), a->wide.rowsA.size() * sizeof(float), a->deviceBytes);
+        if (st == YART_OK) st = upload(&a->dWideRowsBC, a->wide.rowsBC.data(), a->wide.rowsBC.size() * sizeof(float), a->deviceBytes);
         a->hasWide = (st == YART_OK);
     }
     if (st == YART_OK) {
@@ -326,7 +340,8 @@ void yart_accel_destroy(YartAccel* a)
         (void)hipFree(a->dSphIndex);
         (void)hipFree(a->dCounters);
         (void)hipFree(a->dWideNodes);
-        (void)hipFree(a->dWideRows);
+        (void)hipFree(a->dWideRowsA);
+        (void)hipFree(a->dWideRowsBC);
         for (auto& c : a->stagingFree) {
             (void)hipHostFree(c.host);
             (void)hipStreamDestroy(c.stream);
@@ -467,14 +482,15 @@ int yart_accel_get_triaccel(const YartAccel* a, YartTriAccel* out)
 }
 
 size_t yart_accel_num_wide_nodes(const YartAccel* a) { return a ? a->wide.nodes.size() : 0; }
-size_t yart_accel_num_wide_rows(const YartAccel* a) { return a ? a->wide.rows.size() / 4 : 0; }
+size_t yart_accel_num_wide_prims(const YartAccel* a) { return a ? a->wide.rowsA.size() / 4 : 0; }
 int yart_accel_wide_depth(const YartAccel* a) { return a ? a->wide.depth : 0; }
 
-int yart_accel_get_wide(const YartAccel* a, void* nodes_out, void* rows_out)
+int yart_accel_get_wide(const YartAccel* a, void* nodes_out, void* rows_a_out, void* rows_bc_out)
 {
     if (!a) return fail(YART_ERR_INVALID_ARGUMENT, "null argument");
     if (nodes_out) std::memcpy(nodes_out, a->wide.nodes.data(), a->wide.nodes.size() * sizeof(yart::WideNode));
-    if (rows_out) std::memcpy(rows_out, a->wide.rows.data(), a->wide.rows.size() * sizeof(float));
+    if (rows_a_out) std::memcpy(rows_a_out, a->wide.rowsA.data(), a->wide.rowsA.size() * sizeof(float));
+    if (rows_bc_out) std::memcpy(rows_bc_out, a->wide.rowsBC.data(), a->wide.rowsBC.size() * sizeof(float));
     return YART_OK;
 }
 

@@ -28,6 +28,7 @@ __device__ __forceinline__ uint32_t spread3(uint32_t v)      // 9 bits -> every 
 __global__ void __launch_bounds__(256) rayKeys(const float4* __restrict__ rays, uint32_t n,
                                                float lox, float loy, float loz,
                                                float sx, float sy, float sz,
+                                               uint32_t octShift,
                                                uint32_t* __restrict__ keys, uint32_t* __restrict__ ids)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -39,7 +40,9 @@ __global__ void __launch_bounds__(256) rayKeys(const float4* __restrict__ rays, 
     const float fz = fminf(fmaxf((o.z - loz) * sz, 0.0f), 511.0f);
     const uint32_t m = spread3((uint32_t)fx) | (spread3((uint32_t)fy) << 1) | (spread3((uint32_t)fz) << 2);
     const uint32_t oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
-    keys[i] = (m << 3) | oct;
+    // the octant sits above the lowest `octShift` Morton bits: rays of one (2^-(9-octShift/3))^3
+    // cell are grouped by heading before they are ordered by position inside the cell
+    keys[i] = ((m >> octShift) << (octShift + 3)) | (oct << octShift) | (m & ((1u << octShift) - 1u));
     ids[i] = i;
 }
 
@@ -60,7 +63,7 @@ size_t sortWorkspaceBytes(uint32_t n)
     return 3 * alignUp((size_t)n * 4) + alignUp(cubTempBytes(n));
 }
 
-hipError_t sortRays(const float4* rays, uint32_t n, const float lo[3], const float hi[3],
+hipError_t sortRays(const float4* rays, uint32_t n, const float lo[3], const float hi[3], uint32_t octShift,
                     uint32_t* perm, void* workspace, size_t workspaceBytes, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
@@ -77,7 +80,7 @@ hipError_t sortRays(const float4* rays, uint32_t n, const float lo[3], const flo
         s[a] = (ext > 0.0f && ext < 3.0e38f) ? 512.0f / ext : 0.0f;
     }
     hipLaunchKernelGGL(rayKeys, dim3((n + 255) / 256), dim3(256), 0, stream, rays, n,
-                       lo[0], lo[1], lo[2], s[0], s[1], s[2], keysIn, idsIn);
+                       lo[0], lo[1], lo[2], s[0], s[1], s[2], octShift > 27 ? 27u : octShift, keysIn, idsIn);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, keysIn, keysOut, idsIn, perm, (int)n, 0, 30, stream);

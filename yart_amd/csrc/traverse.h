@@ -43,7 +43,8 @@ __host__ __device__ inline bool regularRay(float ox, float oy, float oz, float t
 
 struct WideParams {
     const float4* nodes;        // WideNode array viewed as 4 x float4 per node
-    const float4* rows;         // leaf blocks, 16-byte rows (wide_build.h)
+    const float4* rowsA;        // first-stage leaf rows, 1 per primitive (wide_build.h)
+    const float4* rowsBC;       // second-stage leaf rows, 2 per primitive
     const float4* rays;
     const uint32_t* perm;
     uint32_t n;
@@ -54,6 +55,8 @@ struct WideParams {
     uint32_t* deferFlag;        // word 1 of the same slot: set when a ray was left for the fix-up launch
     uint32_t refillMin;
     uint32_t nodeMin;
+    uint32_t maxBlocksPerCU;    // 0 = as many as fit (8)
+    uint32_t chunk;             // rays a wave takes from its range counter at a time (multiple of 64)
 };
 
 hipError_t launchTraceWide(const WideParams& P, bool any, bool count, bool persistent, int numCUs,
@@ -66,7 +69,7 @@ hipError_t launchTrace(const TraceParams& P, int prim, bool any, bool prune, boo
 // Ray sorting (sort.hip): fills perm[0..n) with ray numbers ordered by a Morton key of
 // the ray origin inside [lo,hi] plus the direction octant.  `keys` and `tmp` are
 // n-element scratch arrays.
-hipError_t sortRays(const float4* rays, uint32_t n, const float lo[3], const float hi[3],
+hipError_t sortRays(const float4* rays, uint32_t n, const float lo[3], const float hi[3], uint32_t octShift,
                     uint32_t* perm, void* workspace, size_t workspaceBytes, hipStream_t stream);
 size_t sortWorkspaceBytes(uint32_t n);
 

@@ -35,10 +35,9 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kLdsStack = 16;
 constexpr int kOvfStack = kWideStack - kLdsStack;
-constexpr uint32_t kChunk = 256;
 constexpr uint32_t kIdle = kWideNone;
 
-__device__ __forceinline__ uint32_t rangeBegin(uint32_t n, uint32_t i)
+__device__ __forceinline__ uint32_t rangeBegin(uint32_t n, uint32_t i, uint32_t kChunk)
 {
     if (i >= 8) return n;
     const uint32_t chunks = (n + kChunk - 1) / kChunk;
@@ -99,6 +98,7 @@ __global__ void __launch_bounds__(kBlock) traceWide(WideParams P)
     WRay r;
     r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = r.tmax = 0.0f;
     uint32_t cur = kIdle;
+    uint32_t pend = kIdle;                         // a leaf set aside while the lane keeps descending
     int sp = 0;
     bool live = false;
     uint32_t rayId = 0;
@@ -116,6 +116,7 @@ __global__ void __launch_bounds__(kBlock) traceWide(WideParams P)
     uint32_t rangesDone = 0;
     const int refillMin = (int)P.refillMin;
     const int nodeMin = (int)P.nodeMin;
+    const uint32_t kChunk = P.chunk;             // rays a wave takes from a range counter at a time
 
     auto push = [&](uint32_t v) {
         if (sp < kLdsStack) ldsStack[sp * kBlock + tid] = v;
@@ -144,18 +145,19 @@ __global__ void __launch_bounds__(kBlock) traceWide(WideParams P)
         cNodes = 0; cTri = 0; cSph = 0;
         sp = 0;
         live = true;
+        pend = kIdle;
         cur = 0u;                                  // root node
     };
 
     for (;;) {
         // ------------------------------------------------------------ fetch work
         if (PERSIST) {
-            const uint64_t idleMask = __ballot(cur == kIdle);
+            const uint64_t idleMask = __ballot(!live);
             const int nIdle = __popcll(idleMask);
             if (!exhausted && (nIdle >= refillMin || idleMask == ~0ull)) {
                 while (chunkNext == chunkEnd && !exhausted) {
                     const uint32_t range = (homeXcd + rangesDone) & 7u;
-                    const uint32_t rBegin = rangeBegin(P.n, range), rEnd = rangeBegin(P.n, range + 1);
+                    const uint32_t rBegin = rangeBegin(P.n, range, kChunk), rEnd = rangeBegin(P.n, range + 1, kChunk);
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(P.workCounter + range * 8, kChunk);
                     base = __builtin_amdgcn_readfirstlane(base) + rBegin;
@@ -165,11 +167,11 @@ __global__ void __launch_bounds__(kBlock) traceWide(WideParams P)
                 if (!exhausted) {
                     const uint32_t avail = chunkEnd - chunkNext;
                     const uint32_t rank = __popcll(idleMask & (laneBit - 1));
-                    if (cur == kIdle && rank < avail) startRay(chunkNext + rank);
+                    if (!live && rank < avail) startRay(chunkNext + rank);
                     chunkNext += ((uint32_t)nIdle < avail) ? (uint32_t)nIdle : avail;
                 }
             }
-            if (__ballot(cur != kIdle) == 0) {
+            if (__ballot(live) == 0) {
                 if (exhausted) break;
                 continue;
             }
@@ -179,14 +181,19 @@ __global__ void __launch_bounds__(kBlock) traceWide(WideParams P)
                 if (slot < P.n) startRay(slot);
                 firstPass = false;
             }
-            if (__ballot(cur != kIdle) == 0) break;
+            if (__ballot(live) == 0) break;
         }
 
         // ------------------------------------------------------------ descend
+        // Speculative descent: a lane that reaches a leaf sets it aside (one per lane) and goes on
+        // with the next node of its stack instead of idling until the wave turns to the leaves; the
+        // leaf is tested in the next leaf phase.  Nodes visited meanwhile are tested against a bound
+        // that does not yet know that leaf's hit -- a little extra work for lanes that stay busy.
         for (;;) {
+            if (pend == kIdle && cur != kIdle && (cur & kWideLeafBit)) { pend = cur; cur = pop(); }
             const uint64_t inner = __ballot((cur & kWideLeafBit) == 0);
             if (inner == 0) break;
-            if (__popcll(inner) < nodeMin && __ballot(cur != kIdle && (cur & kWideLeafBit)) != 0) break;
+            if (__popcll(inner) < nodeMin && __ballot(pend != kIdle) != 0) break;
             if ((cur & kWideLeafBit) == 0) {
                 const float4* p = P.nodes + (size_t)cur * 4;
                 const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
@@ -231,11 +238,14 @@ __global__ void __launch_bounds__(kBlock) traceWide(WideParams P)
         }
 
         // ------------------------------------------------------------ leaf
-        if (cur != kIdle && (cur & kWideLeafBit)) {
-            const uint32_t cnt = ((cur >> 27) & 7u) + 1u;
-            const float4* blk = P.rows + (size_t)(cur & 0x07FFFFFFu) * 4;
+        if (pend != kIdle) {
+            const uint32_t leaf = pend;
+            pend = kIdle;
+            const uint32_t cnt = ((leaf >> 27) & 7u) + 1u;
+            const uint32_t first = leaf & 0x07FFFFFFu;
+            const float4* blk = P.rowsA + first;
             bool stop = false;
-            if ((cur & kWideSphereBit) == 0) {
+            if ((leaf & kWideSphereBit) == 0) {
                 for (uint32_t i = 0; i < cnt; ++i) {
                     const float4 A = blk[i];
                     if (COUNT) ++cTri;
@@ -255,7 +265,7 @@ __global__ void __launch_bounds__(kBlock) traceWide(WideParams P)
                     // order this tree finds them in.
                     const bool tie = !ANY && t == tTri && (int32_t)(kw >> 2) < primTri;
                     if (!((bound > t || tie) && t > 0.0001f)) continue;
-                    const float4 B = blk[cnt + i], C = blk[2 * cnt + i];
+                    const float4 B = P.rowsBC[(size_t)(first + i) * 2], C = P.rowsBC[(size_t)(first + i) * 2 + 1];
                     const float phu = ou + t * du;
                     const float phv = ov + t * dv;
                     const float lambda = phu * B.x + phv * B.y + B.z;
@@ -286,7 +296,7 @@ __global__ void __launch_bounds__(kBlock) traceWide(WideParams P)
                     // a sphere whose float t lies beyond the best triangle cannot be the result
                     // (the triangle is strictly closer); beyond the best sphere neither
                     if (f > fminf(tTri, F)) continue;
-                    const int32_t idx = (int32_t)reinterpret_cast<const uint32_t*>(blk + cnt)[i];
+                    const int32_t idx = (int32_t)__float_as_uint(P.rowsBC[(size_t)(first + i) * 2].x);
                     const bool below = t < (double)f;
                     if (minS < 0 || f < F) { F = f; minS = idx; maxL = below ? idx : -1; }
                     else {
@@ -296,11 +306,10 @@ __global__ void __launch_bounds__(kBlock) traceWide(WideParams P)
                 }
             }
             if (stop) { cur = kIdle; sp = 0; }
-            else cur = pop();
         }
 
         // ------------------------------------------------------------ retire
-        if (cur == kIdle && live) {
+        if (cur == kIdle && pend == kIdle && live) {
             live = false;
             if (ANY) {
                 P.occluded[rayId] = (uint8_t)occ;
@@ -333,8 +342,9 @@ hipError_t launchW(const WideParams& P, bool persistent, int numCUs, hipStream_t
         if (e != hipSuccess) return e;
         if (perCU < 1) perCU = 1;
         if (perCU > 8) perCU = 8;
+        if (P.maxBlocksPerCU && perCU > (int)P.maxBlocksPerCU) perCU = (int)P.maxBlocksPerCU;
         uint32_t grid = (uint32_t)numCUs * (uint32_t)perCU;
-        const uint32_t need = (P.n + kChunk - 1) / kChunk;
+        const uint32_t need = (P.n + P.chunk - 1) / P.chunk;
         const uint32_t needBlocks = (need + 3) / 4;
         if (grid > needBlocks) grid = needBlocks;
         hipLaunchKernelGGL((traceWide<ANY, COUNT, true>), dim3(grid), dim3(kBlock), 0, stream, P);

@@ -1,6 +1,6 @@
 // Host build of the 4-wide triangle+sphere BVH (wide_build.h): binned-SAH binary build on a small
 // thread pool, collapse to four children per node, depth-first emission of 64-byte quantised nodes and
-// 64-byte-aligned leaf blocks.
+// two-stage leaf rows.
 #include "wide_build.h"
 
 #include <algorithm>
@@ -238,17 +238,19 @@ public:
             const float* spheres, WideBvh& out)
         : nodes_(nodes), prims_(prims), tri_(tri), spheres_(spheres), out_(out) { }
 
-    bool tooManyBlocks = false;
+    bool tooManyPrims = false;
 
     void run()
     {
         out_.nodes.clear();
-        out_.rows.clear();
+        out_.rowsA.clear();
+        out_.rowsBC.clear();
         out_.depth = 0;
         out_.numLeaves = 0;
         size_t nTri = 0, nSph = 0;
         for (const auto& p : prims_) ((p.id & kSphereId) ? nSph : nTri)++;
-        out_.rows.reserve((nTri * 3 + nSph * 2) * 4 * 4 / 3 + 64);
+        out_.rowsA.reserve((nTri + nSph) * 4);
+        out_.rowsBC.reserve((nTri + nSph) * 8);
         out_.nodes.reserve(prims_.size() / 2 + 16);
         if (prims_.empty()) {
             out_.nodes.emplace_back();
@@ -352,8 +354,8 @@ private:
 
     uint32_t leaf(const BNode& n)
     {
-        const size_t block = out_.rows.size() / 16;
-        if (block >= kWideMaxBlocks) { tooManyBlocks = true; return kWideNone; }
+        const size_t first = out_.rowsA.size() / 4;
+        if (first + n.count > kWideMaxPrims) { tooManyPrims = true; return kWideNone; }
         const uint32_t cnt = n.count;
         const bool sph = (prims_[n.begin].id & kSphereId) != 0;
         uint32_t ids[kWideMaxLeaf];
@@ -362,29 +364,24 @@ private:
             ids[i] = sph ? (id & ~kSphereId) : tri_.slotOfInput[id];
         }
         std::sort(ids, ids + cnt);                       // in-leaf test order: lowest slot / sphere number first
-        const size_t rows = sph ? cnt + (cnt + 3) / 4 : 3 * static_cast<size_t>(cnt);
-        const size_t padded = (rows + 3) & ~size_t(3);
-        const size_t base = out_.rows.size();
-        out_.rows.resize(base + padded * 4, 0.0f);
-        float* r = out_.rows.data() + base;
-        if (sph) {
-            for (uint32_t i = 0; i < cnt; ++i) {
-                std::memcpy(r + i * 4, spheres_ + static_cast<size_t>(ids[i]) * 4, 16);
-                r[(cnt + i / 4) * 4 + (i & 3)] = bitsFloat(ids[i]);
-            }
-        } else {
-            for (uint32_t i = 0; i < cnt; ++i) {
+        out_.rowsA.resize((first + cnt) * 4, 0.0f);
+        out_.rowsBC.resize((first + cnt) * 8, 0.0f);
+        for (uint32_t i = 0; i < cnt; ++i) {
+            float* A = out_.rowsA.data() + (first + i) * 4;
+            float* B = out_.rowsBC.data() + (first + i) * 8;
+            float* C = B + 4;
+            if (sph) {
+                std::memcpy(A, spheres_ + static_cast<size_t>(ids[i]) * 4, 16);
+                B[0] = bitsFloat(ids[i]);
+            } else {
                 const YartTriAccel& ta = tri_.triaccel[ids[i]];
-                float* A = r + i * 4;
-                float* B = r + (cnt + i) * 4;
-                float* C = r + (2 * cnt + i) * 4;
                 A[0] = ta.n_u; A[1] = ta.n_v; A[2] = ta.n_d; A[3] = bitsFloat(static_cast<uint32_t>(ta.k) | (ids[i] << 2));
-                B[0] = ta.b_u; B[1] = ta.b_v; B[2] = ta.b_d; B[3] = 0.0f;
-                C[0] = ta.c_u; C[1] = ta.c_v; C[2] = ta.c_d; C[3] = 0.0f;
+                B[0] = ta.b_u; B[1] = ta.b_v; B[2] = ta.b_d;
+                C[0] = ta.c_u; C[1] = ta.c_v; C[2] = ta.c_d;
             }
         }
         ++out_.numLeaves;
-        return kWideLeafBit | (sph ? kWideSphereBit : 0u) | ((cnt - 1) << 27) | static_cast<uint32_t>(block);
+        return kWideLeafBit | (sph ? kWideSphereBit : 0u) | ((cnt - 1) << 27) | static_cast<uint32_t>(first);
     }
 
     const std::vector<BNode>& nodes_;
@@ -447,8 +444,8 @@ int buildWideBvh(const float* verts, size_t nVerts, const int32_t* tris, size_t 
         if (!prims.empty()) b.run();
         Emitter e(b.nodes(), prims, tri, spheres, out);
         e.run();
-        if (e.tooManyBlocks) {
-            err = "wide BVH: leaf storage exceeds 2^27 blocks";
+        if (e.tooManyPrims) {
+            err = "wide BVH: more than 2^27 - 1 primitives";
             return YART_ERR_INVALID_ARGUMENT;
         }
         if (3 * out.depth + 1 <= kWideStack) return YART_OK;

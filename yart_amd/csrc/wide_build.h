@@ -4,8 +4,8 @@
 // the NUMBER of scattered line requests and 16-byte lane requests it issues (~1 lane request per
 // clock per CU, ~50 G random lines/s beyond L2), not their bytes.  So a node is ONE 64-byte line
 // holding four quantised child boxes (four 16-byte lane requests per visit instead of the sixteen a
-// binary tree with full-precision boxes needs for the same four boxes), and a leaf is a 64-byte
-// aligned block whose first rows are everything the first rejection test of each primitive needs.
+// binary tree with full-precision boxes needs for the same four boxes), and the
+// leaf data every primitive's first rejection test needs is packed densely, apart from the rest.
 //
 // The reference has no counterpart (its tree is the binary one of src/bvhaccel.cpp, which the
 // library also keeps, bit for bit, for YART_REFERENCE_RULE / YART_REFERENCE_TREE).  A closest hit
@@ -40,24 +40,28 @@ static_assert(sizeof(WideNode) == 64, "wide node is one 64-byte line");
 // ref encoding
 //   interior : bit31 = 0, bits30..0 = node index
 //   leaf     : bit31 = 1, bit30 = kind (0 triangles, 1 spheres), bits29..27 = count - 1,
-//              bits26..0 = leaf block offset in units of 4 rows (64 bytes) into the row array
+//              bits26..0 = index of the leaf's first primitive in the row arrays
 //   kWideNone: empty child slot / "lane has no node"
 constexpr uint32_t kWideLeafBit = 0x80000000u;
 constexpr uint32_t kWideSphereBit = 0x40000000u;
 constexpr uint32_t kWideNone = 0xFFFFFFFFu;
-constexpr uint32_t kWideMaxBlocks = (1u << 27) - 1;
+constexpr uint32_t kWideMaxPrims = (1u << 27) - 1;
 constexpr int kWideMaxLeaf = 8;
 constexpr int kWideStack = 64;          // traversal stack entries per ray (16 in LDS + 48 in scratch)
 
-// Leaf blocks, rows of 16 bytes:
-//   triangles (count c): c rows A = n_u, n_v, n_d, bits(k | slot << 2)   -- slot = index into the
-//                        reference's leaf-ordered TriAccel array = YartHit.prim
-//                        c rows B = b_u, b_v, b_d, -      c rows C = c_u, c_v, c_d, -
-//   spheres   (count c): c rows   = cx, cy, cz, radius;   then ceil(c/4) rows of uint32 sphere numbers
-//   padded to a multiple of 4 rows.
+// Leaf storage is split by WHEN a traversal needs it.  rowsA holds, densely (16 bytes per
+// primitive, a leaf's primitives consecutive, leaves in depth-first order so neighbours in space
+// are neighbours in memory), the row every test starts with:
+//   triangle  n_u, n_v, n_d, bits(k | slot << 2)   -- the plane row of the reference's TriAccel
+//             (include/triaccel.h:16-20); slot = index into the reference's leaf-ordered array = YartHit.prim
+//   sphere    cx, cy, cz, radius
+// rowsBC holds, 32 bytes per primitive at the same index, what only a ray that passed the first
+// test reads: triangle rows b_u, b_v, b_d, - | c_u, c_v, c_d, - ; sphere: its number in Scene::shapes_.
+// Most tests end at the plane distance, so the working set of a batch is the nodes plus rowsA.
 struct WideBvh {
     std::vector<WideNode> nodes;        // nodes[0] = root; 64 bytes each
-    std::vector<float> rows;            // 4 floats per row
+    std::vector<float> rowsA;           // 4 floats per primitive
+    std::vector<float> rowsBC;          // 8 floats per primitive
     int depth = 0;                      // wide levels (root = 1)
     size_t numLeaves = 0;
 };
