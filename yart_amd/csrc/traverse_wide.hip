@@ -54,27 +54,46 @@ struct WRay {
     float ox, oy, oz, dx, dy, dz, ix, iy, iz, tmax;
 };
 
-// A node's grid seen from the ray: per axis t(q) = A + q * B is the distance to grid plane q.
-struct NodeGrid {
-    float Ax, Bx, Ay, By, Az, Bz;
-    uint32_t lx, ly, lz, hx, hy, hz;               // byte c of each = plane of child c
-};
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// Slab test of child C against [0, bound] (minT is 0 for every ray this kernel takes).  The boxes are
-// the engine's own (quantised, conservative), so the arithmetic is free to use fma; the primitive
-// tests below are what has to round like the reference.  Returns the entry distance through tNear.
-template <int C>
-__device__ __forceinline__ bool slab(const NodeGrid& g, float tmax, float bound, float& tNear)
+// Slab test of the four child boxes of a node against [0, bound] (minT is 0 for every ray this
+// kernel takes).  Per axis the distance to grid plane q is t(q) = A + q * B with A = (origin - o) / d,
+// B = scale / d; the sign of d says which of a child's two planes is the entry plane, so the packed
+// plane dwords are swapped once per node instead of taking a min and a max per child and axis.
+// Two children share one packed fma (v_pk_fma_f32).  The boxes are the engine's own (quantised,
+// conservative), so this arithmetic is free to use fma; the primitive tests are what has to round
+// like the reference.  tn[c] = entry distance, returns hit flags in h[c].
+__device__ __forceinline__ void slab4(const float4& q0, const float4& q1, const float4& q2, const WRay& r,
+                                      float bound, float tn[4], bool h[4])
 {
-    const float ax = __builtin_fmaf((float)((g.lx >> (8 * C)) & 255u), g.Bx, g.Ax);
-    const float bx = __builtin_fmaf((float)((g.hx >> (8 * C)) & 255u), g.Bx, g.Ax);
-    const float ay = __builtin_fmaf((float)((g.ly >> (8 * C)) & 255u), g.By, g.Ay);
-    const float by = __builtin_fmaf((float)((g.hy >> (8 * C)) & 255u), g.By, g.Ay);
-    const float az = __builtin_fmaf((float)((g.lz >> (8 * C)) & 255u), g.Bz, g.Az);
-    const float bz = __builtin_fmaf((float)((g.hz >> (8 * C)) & 255u), g.Bz, g.Az);
-    tNear = fmaxf(fmaxf(0.0f, fminf(ax, bx)), fmaxf(fminf(ay, by), fminf(az, bz)));
-    const float tFar = fminf(fminf(bound, fmaxf(ax, bx)), fminf(fmaxf(ay, by), fmaxf(az, bz)));
-    return !(tFar < tNear) && (tFar > 0.0f) && (tNear < tmax);
+    const float Ax = (q0.x - r.ox) * r.ix, Bx = q0.w * r.ix;
+    const float Ay = (q0.y - r.oy) * r.iy, By = q1.x * r.iy;
+    const float Az = (q0.z - r.oz) * r.iz, Bz = q1.y * r.iz;
+    const uint32_t lx = __float_as_uint(q1.z), ly = __float_as_uint(q1.w), lz = __float_as_uint(q2.x);
+    const uint32_t hx = __float_as_uint(q2.y), hy = __float_as_uint(q2.z), hz = __float_as_uint(q2.w);
+    const bool negx = r.ix < 0.0f, negy = r.iy < 0.0f, negz = r.iz < 0.0f;
+    const uint32_t nx = negx ? hx : lx, fx = negx ? lx : hx;      // byte c = entry / exit plane of child c
+    const uint32_t ny = negy ? hy : ly, fy = negy ? ly : hy;
+    const uint32_t nz = negz ? hz : lz, fz = negz ? lz : hz;
+    const f32x2 ax = { Ax, Ax }, bx = { Bx, Bx }, ay = { Ay, Ay }, by = { By, By }, az = { Az, Az }, bz = { Bz, Bz };
+#define YART_PAIR(w, s) (f32x2){ (float)(((w) >> (s)) & 255u), (float)(((w) >> ((s) + 8)) & 255u) }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const f32x2 tnx = __builtin_elementwise_fma(YART_PAIR(nx, 16 * p), bx, ax);
+        const f32x2 tny = __builtin_elementwise_fma(YART_PAIR(ny, 16 * p), by, ay);
+        const f32x2 tnz = __builtin_elementwise_fma(YART_PAIR(nz, 16 * p), bz, az);
+        const f32x2 tfx = __builtin_elementwise_fma(YART_PAIR(fx, 16 * p), bx, ax);
+        const f32x2 tfy = __builtin_elementwise_fma(YART_PAIR(fy, 16 * p), by, ay);
+        const f32x2 tfz = __builtin_elementwise_fma(YART_PAIR(fz, 16 * p), bz, az);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float tNear = fmaxf(fmaxf(tnx[e], tny[e]), fmaxf(tnz[e], 0.0f));
+            const float tFar = fminf(fminf(tfx[e], tfy[e]), fminf(tfz[e], bound));
+            tn[2 * p + e] = tNear;
+            h[2 * p + e] = !(tFar < tNear) && (tFar > 0.0f) && (tNear < r.tmax);
+        }
+    }
+#undef YART_PAIR
 }
 
 #define YART_CSWAP(i, j)                                                   \
@@ -86,7 +105,7 @@ __device__ __forceinline__ bool slab(const NodeGrid& g, float tmax, float bound,
     }
 
 template <bool ANY, bool COUNT, bool PERSIST>
-__global__ void __launch_bounds__(kBlock) traceWide(WideParams P)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) traceWide(WideParams P)
 {
     __shared__ uint32_t ldsStack[kLdsStack * kBlock];
     uint32_t ovf[kOvfStack];
@@ -198,21 +217,14 @@ __global__ void __launch_bounds__(kBlock) traceWide(WideParams P)
                 const float4* p = P.nodes + (size_t)cur * 4;
                 const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
                 const float bound = ANY ? r.tmax : fminf(tTri, F);
-                NodeGrid g;
-                g.Ax = (q0.x - r.ox) * r.ix; g.Bx = q0.w * r.ix;
-                g.Ay = (q0.y - r.oy) * r.iy; g.By = q1.x * r.iy;
-                g.Az = (q0.z - r.oz) * r.iz; g.Bz = q1.y * r.iz;
-                g.lx = __float_as_uint(q1.z); g.ly = __float_as_uint(q1.w); g.lz = __float_as_uint(q2.x);
-                g.hx = __float_as_uint(q2.y); g.hy = __float_as_uint(q2.z); g.hz = __float_as_uint(q2.w);
                 float tn[4];
                 uint32_t rf[4];
                 rf[0] = __float_as_uint(q3.x); rf[1] = __float_as_uint(q3.y);
                 rf[2] = __float_as_uint(q3.z); rf[3] = __float_as_uint(q3.w);
                 bool h[4];
-                h[0] = slab<0>(g, r.tmax, bound, tn[0]) && rf[0] != kWideNone;
-                h[1] = slab<1>(g, r.tmax, bound, tn[1]) && rf[1] != kWideNone;
-                h[2] = slab<2>(g, r.tmax, bound, tn[2]) && rf[2] != kWideNone;
-                h[3] = slab<3>(g, r.tmax, bound, tn[3]) && rf[3] != kWideNone;
+                slab4(q0, q1, q2, r, bound, tn, h);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) h[c] = h[c] && rf[c] != kWideNone;
                 if (COUNT) cNodes += 4;
                 if (ANY) {
                     // order is irrelevant for an occlusion query
