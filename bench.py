@@ -4,8 +4,8 @@
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path -- coherence sort + sphere-tree pass +
-triangle-tree pass (yart_intersect_closest_dev) -- over one batch of synthetic rays
+A "step" is one pass of the hot path -- coherence sort + one traversal of the
+4-wide triangle+sphere tree (yart_intersect_closest_dev) -- over one batch of synthetic rays
 already resident in HBM.  Workload at N=1 (BASELINE.json configs[3], the config the
 metric "Mrays/sec (closest-hit, incoherent paths)" is quoted on; it fits one GPU):
 10 M-triangle random soup + 1 M spheres, 2^24 uniformly random rays (SURVEY.md 8d
@@ -33,13 +33,16 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def algorithmic_bytes(counts, chained):
-    """32 B ray in + 16 B hit out + 32 B per node record + 48 B per
-    triangle record + 16 B per sphere record fetched, per ray and per kernel.
-    counts: [n,4] = tri-tree node records, triangle records, sphere-tree node records,
-    sphere records (the engine's own deterministic traversal, counting kernel)."""
+def algorithmic_bytes(counts, wide, chained):
+    """ray in (32 B) + hit out (16 B) + the records the engine's own traversal
+    fetched, per ray and per kernel, from the counting kernel (include/yart_amd.h):
+      default 4-wide tree : 16 B per child record + 16 B per triangle plane row + 32 B per
+                            second-stage row + 16 B per sphere record
+      reference tree      : 32 B per node record + 48 B per triangle record (+ sphere tree)"""
     c = counts.sum(0).astype(np.float64)
     n = float(len(counts))
+    if wide:
+        return n * (32 + 16) + 16.0 * c[0] + 16.0 * c[1] + 32.0 * c[2] + 16.0 * c[3], 0.0
     tri = n * (32 + 16 + (16 if chained else 0)) + 32.0 * c[0] + 48.0 * c[1]
     sph = (n * (32 + 16) + 32.0 * c[2] + 16.0 * c[3]) if chained else 0.0
     return tri, sph
@@ -56,6 +59,8 @@ def main():
     ap.add_argument("--s", type=float, default=0.005, help="soup edge scale (SURVEY.md 8d sweeps 0.002/0.005/0.01)")
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--static", action="store_true", help="plain grid launch instead of the persistent kernel")
+    ap.add_argument("--reference-tree", action="store_true",
+                    help="traverse the reference's binary tree (sphere pass + triangle pass) instead of the 4-wide tree")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget; 0 disables it")
     args = ap.parse_args()
 
@@ -90,6 +95,9 @@ def main():
         flags |= api.YART_SORT_RAYS
     if args.static:
         flags |= api.YART_STATIC_LAUNCH
+    if args.reference_tree:
+        flags |= api.YART_REFERENCE_TREE
+    wide = not args.reference_tree
 
     # ---- fetch counts of the engine's own traversal -> algorithmic bytes per launch
     d_counts = torch.zeros((args.rays, 4), dtype=torch.int32, device="cuda")
@@ -97,7 +105,7 @@ def main():
     torch.cuda.synchronize()
     counts = d_counts.cpu().numpy().astype(np.uint32)
     del d_counts
-    bytes_tri, bytes_sph = algorithmic_bytes(counts, acc.num_spheres > 0)
+    bytes_tri, bytes_sph = algorithmic_bytes(counts, wide, acc.num_spheres > 0)
     mean_counts = counts.mean(0)
     counted_hits = d_hits.clone()
 
@@ -126,7 +134,7 @@ def main():
 
     # ---- size-independent properties at full size (parity gate, part 1)
     same_as_counted = bool(torch.equal(d_hits.view(torch.int32), counted_hits.view(torch.int32)))            # idempotent / counting variant agrees
-    plain = acc.intersect_closest(d_rays, api.YART_STATIC_LAUNCH)        # unsorted, static grid
+    plain = acc.intersect_closest(d_rays, api.YART_STATIC_LAUNCH | (flags & api.YART_REFERENCE_TREE))   # unsorted, static grid, fix-up launches on
     a, b = api.hits_to_numpy(d_hits), api.hits_to_numpy(plain)
     order_independent = bool(np.array_equal(a["prim"], b["prim"]) and np.array_equal(a["t"].view(np.uint32), b["t"].view(np.uint32)))
     d_occ = acc.intersect_any(d_rays, flags)
@@ -150,7 +158,9 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": "BASELINE configs[3]: random soup %d tris (s=%g) + %d spheres, %d uniformly random rays per GPU, "
-                        "closest-hit, sort=%s, launch=%s" % (args.tris, args.s, args.spheres, args.rays,
+                        "closest-hit, tree=%s, sort=%s, launch=%s" % (args.tris, args.s, args.spheres, args.rays,
+                                                             "reference binary (sphere pass + triangle pass)" if args.reference_tree
+                                                             else "4-wide quantised, triangles+spheres",
                                                              "off" if args.no_sort else "morton+octant",
                                                              "static" if args.static else "persistent"),
             "rays_per_gpu": args.rays, "tris": args.tris, "spheres": args.spheres,
@@ -163,7 +173,8 @@ def main():
     achieved = bytes_tri / t_tri / 1e9 if t_tri > 0 else 0.0
     out["roofline"] = {
         "bound": "hbm",
-        "kernel": "traceKernel<triangles, closest, pruned> (yart_amd/csrc/traverse.hip)",
+        "kernel": ("traceWide<closest> (yart_amd/csrc/traverse_wide.hip)" if wide
+                   else "traceKernel<triangles, closest, pruned> (yart_amd/csrc/traverse.hip)"),
         "achieved": round(achieved, 1),
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
@@ -172,18 +183,21 @@ def main():
         "algorithmic_bytes_per_launch": int(bytes_tri),
         "algorithmic_bytes_per_ray": round(bytes_tri / args.rays, 1),
         "kernel_ms": round(t_tri * 1e3, 3),
-        "per_ray_fetches": {"tri_tree_node_records": round(float(mean_counts[0]), 2),
-                            "triangle_records": round(float(mean_counts[1]), 2),
-                            "sphere_tree_node_records": round(float(mean_counts[2]), 2),
-                            "sphere_records": round(float(mean_counts[3]), 2)},
-        "other_kernels_ms": {"sort": round(t_sort * 1e3, 3), "sphere_tree": round(t_sph * 1e3, 3)},
-        "sphere_kernel_achieved_GBs": round(bytes_sph / t_sph / 1e9, 1) if t_sph > 0 else None,
+        "per_ray_fetches": ({"child_records_16B": round(float(mean_counts[0]), 2),
+                             "triangle_plane_rows_16B": round(float(mean_counts[1]), 2),
+                             "second_stage_rows_32B": round(float(mean_counts[2]), 2),
+                             "sphere_records_16B": round(float(mean_counts[3]), 2)} if wide else
+                            {"tri_tree_node_records_32B": round(float(mean_counts[0]), 2),
+                             "triangle_records_48B": round(float(mean_counts[1]), 2),
+                             "sphere_tree_node_records_32B": round(float(mean_counts[2]), 2),
+                             "sphere_records_16B": round(float(mean_counts[3]), 2)}),
+        "other_kernels_ms": {"sort": round(t_sort * 1e3, 3), "other_passes": round(t_sph * 1e3, 3)},
     }
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(traffic_file):
         try:
             tr = json.load(open(traffic_file))
-            key = "tris=%d,spheres=%d,rays=%d,s=%g" % (args.tris, args.spheres, args.rays, args.s)
+            key = "%stris=%d,spheres=%d,rays=%d,s=%g" % ("" if wide else "reftree,", args.tris, args.spheres, args.rays, args.s)
             if key in tr:
                 out["roofline"]["traffic"] = tr[key]["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = tr[key].get("source")

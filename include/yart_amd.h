@@ -139,13 +139,17 @@ int yart_intersect_closest_dev(YartAccel* accel, const YartRay* d_rays, size_t n
 int yart_intersect_any_dev(YartAccel* accel, const YartRay* d_rays, size_t n,
                            uint8_t* d_occluded, unsigned flags, void* stream);
 
-/* As above and additionally writes, per ray, FOUR uint32 fetch counters:
- *   [0] node (child) records fetched: four per 64-byte node of the default 4-wide tree
- *       (16 bytes each); with YART_REFERENCE_TREE / _RULE two 32-byte records per 64-byte pair of the triangle tree
- *   [1] 48-byte triangle records tested
- *   [2] 32-byte node records fetched from the separate sphere tree (reference-tree path only)
- *   [3] 16-byte sphere records tested
- * -- the terms of the algorithmic bytes per ray.  Diagnostic; slower. */
+/* As above and additionally writes, per ray, FOUR uint32 fetch counters -- the terms of the
+ * algorithmic bytes per ray.  Diagnostic; slower.
+ *   default path (4-wide tree):            YART_REFERENCE_TREE / _RULE (reference's tree):
+ *   [0] 16-byte child records fetched      [0] 32-byte node records, triangle tree
+ *       (four per 64-byte node)
+ *   [1] 16-byte triangle plane rows        [1] 48-byte triangle records tested
+ *   [2] 32-byte second-stage rows          [2] 32-byte node records, sphere tree
+ *       (primitives that passed stage one)
+ *   [3] 16-byte sphere records             [3] 16-byte sphere records
+ * Rays the default path defers to the reference tree (see YART_RAYS_REGULAR) get that
+ * path's counters. */
 int yart_intersect_closest_counted_dev(YartAccel* accel, const YartRay* d_rays, size_t n,
                                        YartHit* d_hits, uint32_t* d_counts,
                                        unsigned flags, void* stream);

@@ -121,6 +121,23 @@ class Oracle:
         return (occ, cnt) if counts else occ
 
 
+def wide_intersect(nodes, rows_a, rows_bc, rays, any_hit=False, counts=False, nthreads=8):
+    """The engine's 4-wide tree (dump of yart_accel_get_wide) walked on the CPU with the default
+    kernel's rule in its deterministic form (cpu_ref.cpp traverseWide)."""
+    build_oracle()
+    L = ctypes.CDLL(ORACLE_SO)
+    L.orc_wide_intersect.argtypes = [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp, c_vp, ctypes.c_int, ctypes.c_int]
+    nodes = np.ascontiguousarray(nodes, np.uint32)
+    rows_a = np.ascontiguousarray(rows_a, np.float32)
+    rows_bc = np.ascontiguousarray(rows_bc, np.float32)
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+    out = np.zeros(len(rays), np.uint8 if any_hit else HIT_DTYPE)
+    cnt = np.zeros((len(rays), 4), np.uint32) if counts else None
+    L.orc_wide_intersect(_p(nodes), _p(rows_a), _p(rows_bc), _p(rays), len(rays), _p(out), _p(cnt),
+                         1 if any_hit else 0, nthreads)
+    return (out, cnt) if counts else out
+
+
 class Reference:
     """The real reference (ref_shim.cpp around /root/reference)."""
 

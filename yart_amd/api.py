@@ -179,12 +179,15 @@ class Accel:
         return lib().yart_accel_wide_depth(self._h)
 
     def wide(self):
-        """-> (nodes uint32 [nNodes, 16], rows float32 [nRows, 4]) of the 4-wide tree (wide_build.h)."""
+        """-> (nodes uint32 [nNodes, 16], rowsA float32 [nPrims, 4], rowsBC float32 [nPrims, 8]) of the
+        4-wide tree (yart_amd/csrc/wide_build.h)."""
         L = lib()
+        n = L.yart_accel_num_wide_prims(self._h)
         nodes = np.zeros((L.yart_accel_num_wide_nodes(self._h), 16), np.uint32)
-        rows = np.zeros((L.yart_accel_num_wide_prims(self._h), 4), np.float32)
-        _check(L.yart_accel_get_wide(self._h, _p(nodes), _p(rows)))
-        return nodes, rows
+        rows_a = np.zeros((n, 4), np.float32)
+        rows_bc = np.zeros((n, 8), np.float32)
+        _check(L.yart_accel_get_wide(self._h, _p(nodes), _p(rows_a), _p(rows_bc)))
+        return nodes, rows_a, rows_bc
 
     def profile(self, enable=True):
         _check(lib().yart_accel_profile_enable(self._h, 1 if enable else 0))

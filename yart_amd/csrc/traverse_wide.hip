@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
     float F = 0.0f;                                // best sphere: float t, candidates bookkeeping
     int32_t minS = -1, maxL = -1;
     uint32_t occ = 0;
-    uint32_t cNodes = 0, cTri = 0, cSph = 0;
+    uint32_t cNodes = 0, cTri = 0, cSph = 0, cStage2 = 0;
 
     uint32_t chunkNext = 0, chunkEnd = 0;
     bool exhausted = false;
@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
         r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
         tTri = r.tmax; hu = 0.0f; hv = 0.0f; primTri = -1;
         F = __builtin_inff(); minS = -1; maxL = -1; occ = 0;
-        cNodes = 0; cTri = 0; cSph = 0;
+        cNodes = 0; cTri = 0; cSph = 0; cStage2 = 0;
         sp = 0;
         live = true;
         pend = kIdle;
@@ -226,15 +226,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
 #pragma unroll
                 for (int c = 0; c < 4; ++c) h[c] = h[c] && rf[c] != kWideNone;
                 if (COUNT) cNodes += 4;
-                if (ANY) {
-                    // order is irrelevant for an occlusion query
-                    uint32_t next = kIdle;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        if (h[c]) { if (next == kIdle) next = rf[c]; else push(rf[c]); }
-                    }
-                    cur = (next == kIdle) ? pop() : next;
-                } else {
+                {
                     // nearest child next, the others pushed far to near
                     const float big = 3.0e38f;
 #pragma unroll
@@ -278,6 +270,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
                     const bool tie = !ANY && t == tTri && (int32_t)(kw >> 2) < primTri;
                     if (!((bound > t || tie) && t > 0.0001f)) continue;
                     const float4 B = P.rowsBC[(size_t)(first + i) * 2], C = P.rowsBC[(size_t)(first + i) * 2 + 1];
+                    if (COUNT) ++cStage2;
                     const float phu = ou + t * du;
                     const float phv = ov + t * dv;
                     const float lambda = phu * B.x + phv * B.y + B.z;
@@ -309,6 +302,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
                     // (the triangle is strictly closer); beyond the best sphere neither
                     if (f > fminf(tTri, F)) continue;
                     const int32_t idx = (int32_t)__float_as_uint(P.rowsBC[(size_t)(first + i) * 2].x);
+                    if (COUNT) ++cStage2;
                     const bool below = t < (double)f;
                     if (minS < 0 || f < F) { F = f; minS = idx; maxL = below ? idx : -1; }
                     else {
@@ -336,7 +330,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
             }
             if (COUNT) {
                 uint32_t* c = P.counts + (size_t)rayId * 4;
-                c[0] = cNodes; c[1] = cTri; c[2] = 0; c[3] = cSph;
+                c[0] = cNodes; c[1] = cTri; c[2] = cStage2; c[3] = cSph;
             }
         }
     }
