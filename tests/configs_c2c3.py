@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Parity-checked measurements of the BASELINE.json configurations that are not the bench line
-(C1 is tests/test_trace_dropin.py, C4 is bench.py, C5 is tools/render_tiles.py).
+(C1 is tests/test_trace_dropin.py, C4 is bench.py, C5 is tools/render_tiles.py).  Lives under tests/ because it checks every batch against the oracle.
 
-    python tools/bench_configs.py [--tris 262144] [--width 1920 --height 1080] [--spp 4] [--depth 8]
+    python tests/configs_c2c3.py [--tris 262144] [--width 1920 --height 1080] [--spp 4] [--depth 8]
 
 C2  pinhole primary rays, one per pixel centre (Camera::sample, include/camera.h:24-31), into the
     Sponza-class stand-in scene (yart_amd/scenes.py: no assets and no network in the build environment).
