@@ -254,7 +254,9 @@ def reference_trace_cornell(width, height, pixels, mode=0, nthreads=8, engine=No
       mode 1 -> rgb, closest_rays [m,8], shadow_rays [k,8]  (the ray stream trace() issued)
       mode 2 -> rgb, n_engine_calls; `engine` = (closest_fn_addr, any_fn_addr, accel_handle, flags):
                 every Scene::intersect / intersectShadow of trace() is answered by those C-ABI
-                entry points through the reference's virtual Shape::intersect hook."""
+                entry points through the reference's virtual Shape::intersect hook.
+      mode 3 -> rgb, stats; trace() restated as the integrator of yart_amd/cxx/wavefront.hpp: all
+                listed pixels in flight, batched engine calls."""
     L = ctypes.CDLL(so or REF_SO)
     L.ref_trace_cornell.restype = ctypes.c_long
     L.ref_trace_cornell.argtypes = [ctypes.c_int, ctypes.c_int, c_vp, c_sz, ctypes.c_int, ctypes.c_int, c_vp,
@@ -279,4 +281,8 @@ def reference_trace_cornell(width, height, pixels, mode=0, nthreads=8, engine=No
         if rc < 0:
             raise RuntimeError("engine call failed inside trace()")
         return rgb, int(rc)
+    if mode == 3:
+        if rc < 0:
+            raise RuntimeError("engine call failed inside the wavefront driver")
+        return rgb, dict(rays=int(rc), closest_batches=int(ncl.value), largest_batch=int(nsh.value))
     return rgb

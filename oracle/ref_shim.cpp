@@ -46,6 +46,8 @@
 // pixel, for the caller-harness fixtures.  Renderer::render / TileTask come
 // along and need the reference's scheduler at link time (src/scheduler.cpp, built beside this).
 #include "../src/renderer.cpp"
+// product header under test: the batched driver the restated integrator below plugs into
+#include "../yart_amd/cxx/wavefront.hpp"
 
 namespace {
 
@@ -221,6 +223,29 @@ public:
 };
 
 struct EngineHit { float t, u, v; int32_t prim; };          // = YartHit
+
+// What the reference derives after a hit (src/bvhaccel.cpp:283-292, include/sphere.h:79-83), from the
+// engine's (t, u, v, prim) with the reference's own mesh / sphere accessors.
+void fillHitInfo(const Scene& geometry, const TriAccel* leafOrder, const Ray& ray, const EngineHit& h, RayHitInfo* hitInfo)
+{
+    hitInfo->t = h.t;
+    hitInfo->u = h.u;
+    hitInfo->v = h.v;
+    if (h.prim >= 0) {
+        const TriAccel& ta = leafOrder[h.prim];
+        const auto& mesh = geometry.meshes_[ta.meshIdx];
+        hitInfo->normal = mesh.getNormal(ta.triIdx);
+        hitInfo->shadingNormal = mesh.getShadingNormal(ta.triIdx, h.u, h.v);
+        hitInfo->bsdf = mesh.getBsdf();
+        hitInfo->areaLight = nullptr;
+    } else {
+        const auto* sp = static_cast<const Sphere*>(geometry.shapes_[-(h.prim + 2)].get());
+        hitInfo->normal = normal(ray.orig + ray.dir * hitInfo->t - sp->position_);
+        hitInfo->shadingNormal = hitInfo->normal;
+        hitInfo->bsdf = sp->bsdf_.get();
+        hitInfo->areaLight = sp->getLight();
+    }
+}
 typedef int (*EngineClosestFn)(void* accel, const void* rays, size_t n, void* hits, unsigned flags);
 typedef int (*EngineAnyFn)(void* accel, const void* rays, size_t n, uint8_t* occluded, unsigned flags);
 
@@ -243,23 +268,7 @@ public:
         if (closest_(accel_, &ray, 1, &h, flags_) != 0) { failed = true; return false; }
         ++numClosest;
         if (h.prim == -1 || !(h.t < hitInfo->t)) return false;
-        hitInfo->t = h.t;
-        hitInfo->u = h.u;
-        hitInfo->v = h.v;
-        if (h.prim >= 0) {                                  // src/bvhaccel.cpp:283-292
-            const TriAccel& ta = leafOrder_[h.prim];
-            const auto& mesh = geometry_.meshes_[ta.meshIdx];
-            hitInfo->normal = mesh.getNormal(ta.triIdx);
-            hitInfo->shadingNormal = mesh.getShadingNormal(ta.triIdx, h.u, h.v);
-            hitInfo->bsdf = mesh.getBsdf();
-            hitInfo->areaLight = nullptr;
-        } else {                                            // include/sphere.h:79-83
-            const auto* sp = static_cast<const Sphere*>(geometry_.shapes_[-(h.prim + 2)].get());
-            hitInfo->normal = normal(ray.orig + ray.dir * hitInfo->t - sp->position_);
-            hitInfo->shadingNormal = hitInfo->normal;
-            hitInfo->bsdf = sp->bsdf_.get();
-            hitInfo->areaLight = sp->getLight();
-        }
+        fillHitInfo(geometry_, leafOrder_, ray, h, hitInfo);
         return true;
     }
     Vector3f sample(float, float, float* pdf) const override { *pdf = 0.0f; return Vector3f(0.0f, 0.0f, 0.0f); }
@@ -275,6 +284,129 @@ private:
     EngineAnyFn any_;
     void* accel_;
     unsigned flags_;
+};
+
+
+// trace() (src/renderer.cpp:29-136) restated as the three callbacks of yart_amd::PathIntegrator
+// (yart_amd/cxx/wavefront.hpp): the same statements on the reference's own Rng / Camera / Light / Bsdf /
+// Frame / Spectrum objects, cut at the two intersection calls, state kept per pixel.  Every pixel
+// consumes its random numbers in trace()'s order (this TU is compiled by the same g++, so the
+// unspecified evaluation order of the paired randomFloat() arguments, :47-50, :98-99, :118-119, is the
+// one trace() gets), hence a batched run must reproduce trace()'s pixels bit for bit.
+class RefTraceIntegrator : public yart_amd::PathIntegrator {
+public:
+    RefTraceIntegrator(const Scene& geometry, const TriAccel* leafOrder, Camera& camera, const int32_t* pixels, size_t n)
+        : geometry_(geometry), leafOrder_(leafOrder), camera_(camera), slots_(n)
+    {
+        for (size_t i = 0; i < n; ++i) {
+            Slot& s = slots_[i];
+            s.x = pixels[i * 2 + 0];
+            s.y = pixels[i * 2 + 1];
+            s.rng = Rng(s.y * camera.getWidth() + s.x);                                   // :33
+            s.finalColor = Spectrum(0.0f);
+        }
+    }
+
+    bool nextPath(size_t slot, YartRay* ray) override
+    {
+        Slot& s = slots_[slot];
+        if (s.k == kMaxIter) {
+            if (!s.written) { camera_.accumulate(s.x, s.y, s.finalColor.toRGB()); s.written = true; }   // :135
+            return false;
+        }
+        s.color = Spectrum(0.0f);                                                         // :44-45
+        s.pathWeight = Spectrum(1.0f);
+        s.currentRay = camera_.sample(s.x + s.rng.randomFloat() - 0.5f, s.y + s.rng.randomFloat() - 0.5f);   // :47-50
+        s.evaluateDirectLightHit = true;                                                  // :52
+        s.bounce = 0;
+        std::memcpy(ray, &s.currentRay, sizeof(Ray));
+        return true;
+    }
+
+    bool onClosest(size_t slot, const YartRay&, const YartHit& hit, YartRay* shadowRay) override
+    {
+        using std::abs;
+        Slot& s = slots_[slot];
+        RayHitInfo& isect = s.isect;
+        isect.t = s.currentRay.maxT;                                                      // include/scene.h:139-140
+        isect.areaLight = nullptr;
+        if (hit.prim == -1) return endSample(s);                                          // :59-60
+        EngineHit h{ hit.t, hit.u, hit.v, hit.prim };
+        fillHitInfo(geometry_, leafOrder_, s.currentRay, h, &isect);
+        if (s.evaluateDirectLightHit && isect.areaLight) s.color += s.pathWeight * isect.areaLight->intensity();   // :62-64
+        if (!isect.bsdf) return endSample(s);                                             // :66-67
+        s.intersection = s.currentRay.orig + (s.currentRay.dir * isect.t);                // :74
+        auto norm = isect.shadingNormal;
+        s.nl = dot(isect.normal, s.currentRay.dir) < 0.0f ? norm : norm * -1.0f;          // :76
+        s.hitFrame = Frame(s.nl);
+        s.wo = s.hitFrame.toLocal(-s.currentRay.dir);
+        const auto& lights = geometry_.getLights();
+        s.numLights = static_cast<int32_t>(lights.size());
+        int32_t lightIdx = std::min(static_cast<int32_t>(s.rng.randomFloat() * s.numLights), s.numLights - 1);   // :90-93
+        const auto& light = lights[lightIdx];
+        float eps;
+        Vector3f sampledPosition;
+        s.lightEmission = light->sample(s.intersection, &s.wi, &s.pdf, &sampledPosition, &eps,
+            s.rng.randomFloat(), s.rng.randomFloat());                                    // :98-99
+        auto lightRay = Ray(s.intersection + s.wi * EPS, s.wi);                           // :101-102
+        lightRay.maxT = length(s.intersection - sampledPosition) - eps;
+        std::memcpy(shadowRay, &lightRay, sizeof(Ray));
+        return true;
+    }
+
+    bool onShadow(size_t slot, bool occluded, YartRay* nextRay) override
+    {
+        using std::abs;
+        Slot& s = slots_[slot];
+        RayHitInfo& isect = s.isect;
+        if (!occluded) {                                                                  // :104-108
+            Spectrum f = isect.bsdf->f(s.wo, s.wi);
+            s.color = s.color + (s.pathWeight * f * s.lightEmission
+                * (abs(dot(s.nl, s.wi)) / s.pdf) * (float)s.numLights);
+        }
+        float continueProbability = s.pathWeight.y();                                     // :113-115
+        if (s.rng.randomFloat() > continueProbability) return endSample(s);
+        s.pathWeight /= continueProbability;                                              // :117
+        Vector3f wi;
+        float pdf;
+        Spectrum refl = isect.bsdf->sample(s.wo, &wi, s.rng.randomFloat(), s.rng.randomFloat(), &pdf);   // :118-119
+        if (refl.y() == 0.0f) return endSample(s);                                        // :121-122
+        s.evaluateDirectLightHit = isect.bsdf->isDelta();                                 // :124
+        Vector3f dir = s.hitFrame.toWorld(wi);                                            // :126
+        s.pathWeight = s.pathWeight * refl * abs(dot(dir, s.nl)) / pdf;                   // :128
+        s.currentRay = { s.intersection + dir * EPS, dir };                               // :129
+        if (++s.bounce == 10) return endSample(s);                                        // :58
+        std::memcpy(nextRay, &s.currentRay, sizeof(Ray));
+        return true;
+    }
+
+private:
+    static constexpr int kMaxIter = 4096;                                                 // :36
+    struct Slot {
+        Rng rng;
+        int32_t x = 0, y = 0;
+        int k = 0, bounce = 0;
+        bool written = false, evaluateDirectLightHit = true;
+        Spectrum finalColor, color, pathWeight, lightEmission;
+        Ray currentRay{ Vector3f(0.0f, 0.0f, 0.0f), Vector3f(0.0f, 0.0f, 1.0f) };
+        RayHitInfo isect;
+        Vector3f intersection, nl, wo, wi;
+        Frame hitFrame;
+        float pdf = 0.0f;
+        int32_t numLights = 0;
+    };
+    static bool endSample(Slot& s)
+    {
+        static const float invMaxIter = 1.0f / kMaxIter;                                  // :37
+        s.finalColor = s.finalColor + (s.color * invMaxIter);                             // :132
+        ++s.k;
+        return false;
+    }
+
+    const Scene& geometry_;
+    const TriAccel* leafOrder_;
+    Camera& camera_;
+    std::vector<Slot> slots_;
 };
 
 // The camera of src/rt.cpp:22-28 at the given resolution.
@@ -296,6 +428,9 @@ extern "C" {
 //           ref_free); pixel order, single thread, so the order is trace()'s own
 //   mode 2  intersection through the engine callbacks (EngineShape); accel / flags are passed on.
 //           Returns the number of engine calls made, or -1 if an engine call failed.
+//   mode 3  trace() restated as a yart_amd::PathIntegrator, driven by yart_amd::WavefrontDriver: all
+//           listed pixels in flight at once, one closest-hit batch + one shadow batch per round.
+//           Returns the number of rays traced; *nClosest = closest-hit batches, *nShadow = largest batch.
 long ref_trace_cornell(int width, int height, const int32_t* pixels, size_t nPixels, int mode, int nthreads,
                        float* rgbOut, float** closestLog, size_t* nClosest, float** shadowLog, size_t* nShadow,
                        EngineClosestFn closestFn, EngineAnyFn anyFn, void* accel, unsigned flags)
@@ -305,6 +440,31 @@ long ref_trace_cornell(int width, int height, const int32_t* pixels, size_t nPix
     std::unique_ptr<Scene> scene;
     std::shared_ptr<EngineShape> engine;
     std::unique_ptr<BvhAccel> leafOrderSource;
+    if (mode == 3) {
+        // the batched driver (yart_amd/cxx/wavefront.hpp) with trace() restated as its integrator
+        leafOrderSource = std::make_unique<BvhAccel>(cornell);
+        RefTraceIntegrator integ(cornell, leafOrderSource->triangles_, camera, pixels, nPixels);
+        yart_amd::Engine eng;
+        eng.closest = reinterpret_cast<int (*)(YartAccel*, const YartRay*, size_t, YartHit*, unsigned)>(closestFn);
+        eng.any = reinterpret_cast<int (*)(YartAccel*, const YartRay*, size_t, uint8_t*, unsigned)>(anyFn);
+        eng.accel = static_cast<YartAccel*>(accel);
+        eng.flags = flags;
+        yart_amd::WavefrontDriver driver(eng, nPixels, nthreads);
+        yart_amd::WavefrontStats st;
+        try {
+            st = driver.run(integ);
+        } catch (const std::exception& e) {
+            fprintf(stderr, "ref_trace_cornell: %s\n", e.what());
+            return -1;
+        }
+        for (size_t i = 0; i < nPixels; ++i) {
+            const RGBColor& c = camera.sensor_.buffer_[(size_t)pixels[i * 2 + 1] * width + pixels[i * 2 + 0]];
+            rgbOut[i * 3 + 0] = c.r; rgbOut[i * 3 + 1] = c.g; rgbOut[i * 3 + 2] = c.b;
+        }
+        if (nClosest) *nClosest = st.closestBatches;
+        if (nShadow) *nShadow = st.largestBatch;
+        return (long)(st.closestRays + st.shadowRays);
+    }
     if (mode == 2) {
         // prim ids of the engine index the reference's leaf-ordered TriAccel array
         leafOrderSource = std::make_unique<BvhAccel>(cornell);
@@ -459,6 +619,29 @@ void ref_intersect_shadow(void* h, const float* rays, size_t n, uint8_t* out, in
             out[i] = scene.intersectShadow(ray) ? 1 : 0;
         }
     });
+}
+
+// The reference itself behind the two engine signatures of include/yart_amd.h (accel = a RefScene*):
+// lets the CPU tests run everything that is written against those signatures -- the batched driver,
+// the EngineShape hook -- without a GPU.
+int ref_engine_closest(void* h, const void* rays, size_t n, void* hits, unsigned)
+{
+    std::vector<HitOut> tmp(n);
+    ref_intersect(h, static_cast<const float*>(rays), n, tmp.data(), 1);
+    auto* out = static_cast<EngineHit*>(hits);
+    for (size_t i = 0; i < n; ++i) {
+        out[i].t = tmp[i].t;
+        out[i].u = tmp[i].hit ? tmp[i].u : 0.0f;
+        out[i].v = tmp[i].hit ? tmp[i].v : 0.0f;
+        out[i].prim = tmp[i].hit ? tmp[i].prim : -1;
+    }
+    return 0;
+}
+
+int ref_engine_any(void* h, const void* rays, size_t n, uint8_t* occluded, unsigned)
+{
+    ref_intersect_shadow(h, static_cast<const float*>(rays), n, occluded, 1);
+    return 0;
 }
 
 // Throughput loop for the CPU baseline: nothing but Scene::intersect per ray,

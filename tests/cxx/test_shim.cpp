@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../yart_amd/cxx/yart_shim.hpp"
+#include "../../yart_amd/cxx/wavefront.hpp"
 
 using namespace yart_amd;
 
@@ -19,6 +20,22 @@ template <class T> static std::vector<T> readArr(FILE* f)
     if (n && fread(v.data(), sizeof(T), n, f) != n) { fprintf(stderr, "short read\n"); exit(2); }
     return v;
 }
+
+// One closest-hit ray and one shadow ray per slot through the batched driver: must give what the
+// direct batch calls give.
+struct OneShot : yart_amd::PathIntegrator {
+    const YartRay* rays; const YartRay* shadow; size_t nShadow;
+    std::vector<uint8_t> started; std::vector<int32_t> prim; std::vector<uint8_t> occ;
+    bool nextPath(size_t s, YartRay* r) override { if (started[s]) return false; started[s] = 1; *r = rays[s]; return true; }
+    bool onClosest(size_t s, const YartRay&, const YartHit& h, YartRay* sh) override
+    {
+        prim[s] = h.prim;
+        if (s >= nShadow) return false;
+        *sh = shadow[s];
+        return true;
+    }
+    bool onShadow(size_t s, bool o, YartRay*) override { occ[s] = o ? 1 : 0; return false; }
+};
 
 int main(int argc, char** argv)
 {
@@ -99,6 +116,19 @@ int main(int argc, char** argv)
     const size_t singleS = m < 256 ? m : 256;
     for (size_t i = 0; i < singleS; ++i) occ[i] = scene.intersectShadow(S[i]) ? 1 : 0;
     if (m > singleS) scene.intersectShadowBatch(S + singleS, m - singleS, occ.data() + singleS);
+
+    {
+        OneShot integ;
+        integ.rays = reinterpret_cast<const YartRay*>(rays.data());
+        integ.shadow = reinterpret_cast<const YartRay*>(shadow.data());
+        integ.nShadow = m;
+        integ.started.assign(n, 0); integ.prim.assign(n, -7); integ.occ.assign(n, 9);
+        yart_amd::WavefrontDriver driver(yart_amd::linkedEngine(scene.accel()->handle(), argc > 3 ? YART_REFERENCE_RULE : YART_DEFAULT), n, 4);
+        const yart_amd::WavefrontStats st = driver.run(integ);
+        if (st.closestRays != n || st.shadowRays != (m < n ? m : n)) { fprintf(stderr, "driver ray counts\n"); return 5; }
+        for (size_t i = 0; i < n; ++i) if (integ.prim[i] != prim[i]) { fprintf(stderr, "driver prim differs at %zu\n", i); return 5; }
+        for (size_t i = 0; i < m && i < n; ++i) if (integ.occ[i] != occ[i]) { fprintf(stderr, "driver occlusion differs at %zu\n", i); return 5; }
+    }
 
     FILE* g = fopen(argv[2], "wb");
     if (!g) return 2;

@@ -17,12 +17,13 @@ EXE = os.path.join(ROOT, "tests", "cxx", "_build", "test_shim")
 
 def build_exe():
     os.makedirs(os.path.dirname(EXE), exist_ok=True)
-    deps = [SRC, os.path.join(ROOT, "yart_amd", "cxx", "yart_shim.hpp"), os.path.join(ROOT, "include", "yart_amd.h")]
+    deps = [SRC, os.path.join(ROOT, "yart_amd", "cxx", "yart_shim.hpp"), os.path.join(ROOT, "yart_amd", "cxx", "wavefront.hpp"),
+            os.path.join(ROOT, "include", "yart_amd.h")]
     if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(d) for d in deps):
         lib_dir = os.path.join(ROOT, "yart_amd")
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", SRC, "-o", EXE,
                                "-L" + lib_dir, "-lyart_amd", "-Wl,-rpath," + lib_dir,
-                               "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+                               "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lpthread"])
     return EXE
 
 

@@ -38,6 +38,55 @@ def test_reference_trace_matches_golden_pixels_and_stream():
     assert int(at_camera.sum()) == 4 * 4096
 
 
+def _reference_engine(g):
+    """The reference itself behind the two C-ABI engine signatures (oracle/ref_shim.cpp): lets the
+    EngineShape hook and the batched driver be exercised without a GPU."""
+    ref = orc.Reference(g["verts"], g["tris"], g["spheres"])
+    fc = ctypes.cast(ref.lib.ref_engine_closest, ctypes.c_void_p)
+    fa = ctypes.cast(ref.lib.ref_engine_any, ctypes.c_void_p)
+    return ref, (fc, fa, ref.h, 0)
+
+
+@needs_ref
+@pytest.mark.parametrize("mode", [2, 3], ids=["shape_hook", "wavefront_driver"])
+def test_harness_plumbing_on_cpu(mode):
+    """CPU: with the reference answering the rays, the one-ray Shape hook (mode 2) and the batched
+    driver of yart_amd/cxx/wavefront.hpp with trace() restated as its integrator (mode 3) both give
+    trace()'s own pixels bit for bit -- so any difference seen on the GPU is the engine's."""
+    g = load_golden("g4_trace.npz")
+    w, h = (int(v) for v in g["frame"])
+    ref, engine = _reference_engine(g)
+    rgb, info = orc.reference_trace_cornell(w, h, g["pixels"], mode=mode, nthreads=1, engine=engine)
+    assert np.array_equal(rgb.view(np.uint32), g["rgb"].view(np.uint32))
+    total = int(g["stream_counts"].sum())
+    assert (info if mode == 2 else info["rays"]) == total
+    if mode == 3:
+        assert info["largest_batch"] == len(g["pixels"])       # every pixel in flight at once
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("rule", ["reference", "default"])
+def test_wavefront_driver_reproduces_reference_image(rule):
+    """the batched driver (yart_amd/cxx/wavefront.hpp) feeding the GPU engine, with the
+    reference's trace() restated as its integrator (reference BSDFs / lights / RNG): bit-identical
+    pixels, RMSE 0."""
+    g = load_golden("g4_trace.npz")
+    w, h = (int(v) for v in g["frame"])
+    acc = api.Accel(g["verts"], g["tris"], g["spheres"], device=0)
+    L = api.lib()
+    fc = ctypes.cast(L.yart_intersect_closest, ctypes.c_void_p)
+    fa = ctypes.cast(L.yart_intersect_any, ctypes.c_void_p)
+    flags = api.YART_REFERENCE_RULE if rule == "reference" else 0
+    rgb, info = orc.reference_trace_cornell(w, h, g["pixels"], mode=3, nthreads=4, engine=(fc, fa, acc._h, flags))
+    print("wavefront driver: %d rays in %d closest-hit batches (largest %d)" % (info["rays"], info["closest_batches"], info["largest_batch"]))
+    rmse = float(np.sqrt(np.mean((rgb.astype(np.float64) - g["rgb"].astype(np.float64)) ** 2)))
+    assert rmse <= RMSE_BOUND, rmse
+    assert np.array_equal(rgb.view(np.uint32), g["rgb"].view(np.uint32))
+    assert info["rays"] == int(g["stream_counts"].sum())
+    acc.close()
+
+
 @needs_ref
 @pytest.mark.gpu
 @pytest.mark.parametrize("rule", ["reference", "default"])

@@ -1,0 +1,167 @@
+// wavefront.hpp -- batched driver for a path tracer built like yart's.  Header-only C++17.
+//
+// The reference's integrator is synchronous and per pixel: trace() (src/renderer.cpp:29-136) calls
+// Scene::intersect, shades, calls Scene::intersectShadow, samples the BSDF, and loops -- one ray per
+// call, from 8 threads (src/scheduler.cpp:20).  The engine wants 10^5..10^8 rays per call.  This
+// driver turns the loop inside out WITHOUT touching the integrator's arithmetic or the order in which
+// a pixel consumes its random numbers: the integrator is cut at its two intersection calls into three
+// callbacks, every pixel in flight ("slot") advances through them in its own order, and all slots
+// that wait for the same kind of answer are traced as one batch.
+//
+//   nextPath   src/renderer.cpp:43-52   start the slot's next sample: camera ray (false: slot done)
+//   onClosest  src/renderer.cpp:59-102  closest-hit answer -> shading set-up, light sample, shadow ray
+//   onShadow   src/renderer.cpp:104-129 occlusion answer -> direct light, roulette, BSDF sample, next ray
+//
+// Callbacks of DIFFERENT slots run concurrently (host threads); a slot's callbacks run in order.
+// The engine is reached through two function pointers with the signatures of
+// yart_intersect_closest / yart_intersect_any (include/yart_amd.h); linkedEngine() binds the
+// library's own.  With the reference's trace() restated as such an integrator the driver reproduces
+// the reference's image bit for bit (tests/test_trace_dropin.py).
+#pragma once
+
+#include <atomic>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/yart_amd.h"
+
+namespace yart_amd {
+
+class PathIntegrator {
+public:
+    virtual ~PathIntegrator() = default;
+    virtual bool nextPath(size_t slot, YartRay* ray) = 0;
+    virtual bool onClosest(size_t slot, const YartRay& ray, const YartHit& hit, YartRay* shadowRay) = 0;
+    virtual bool onShadow(size_t slot, bool occluded, YartRay* nextRay) = 0;
+};
+
+struct Engine {
+    int (*closest)(YartAccel*, const YartRay*, size_t, YartHit*, unsigned) = nullptr;
+    int (*any)(YartAccel*, const YartRay*, size_t, uint8_t*, unsigned) = nullptr;
+    YartAccel* accel = nullptr;
+    unsigned flags = YART_DEFAULT;
+};
+
+inline Engine linkedEngine(YartAccel* accel, unsigned flags = YART_DEFAULT)
+{
+    Engine e;
+    e.closest = &yart_intersect_closest;
+    e.any = &yart_intersect_any;
+    e.accel = accel;
+    e.flags = flags;
+    return e;
+}
+
+struct WavefrontStats {
+    uint64_t closestRays = 0, shadowRays = 0, closestBatches = 0, shadowBatches = 0, paths = 0;
+    size_t largestBatch = 0;
+};
+
+class WavefrontDriver {
+public:
+    WavefrontDriver(Engine engine, size_t slots, int hostThreads = 8)
+        : engine_(engine), nSlots_(slots), nThreads_(hostThreads < 1 ? 1 : hostThreads) { }
+
+    WavefrontStats run(PathIntegrator& integ)
+    {
+        enum : uint8_t { kIdle, kClosest, kShadow, kDone };
+        std::vector<uint8_t> state(nSlots_, kIdle);
+        std::vector<YartRay> ray(nSlots_);              // the slot's pending ray
+        std::vector<uint32_t> ids;
+        std::vector<YartRay> batch;
+        std::vector<YartHit> hits;
+        std::vector<uint8_t> occ;
+        WavefrontStats st;
+        ids.reserve(nSlots_);
+        for (;;) {
+            // slots without a path start their next one (sequential per slot, parallel across slots)
+            std::atomic<uint64_t> started{ 0 };
+            parallelFor(nSlots_, [&](size_t s) {
+                if (state[s] != kIdle) return;
+                if (integ.nextPath(s, &ray[s])) { state[s] = kClosest; started.fetch_add(1, std::memory_order_relaxed); }
+                else state[s] = kDone;
+            });
+            st.paths += started.load();
+
+            collect(state, kClosest, ids);
+            if (!ids.empty()) {
+                gather(ids, ray, batch);
+                hits.resize(ids.size());
+                check(engine_.closest(engine_.accel, batch.data(), batch.size(), hits.data(), engine_.flags));
+                st.closestRays += ids.size();
+                st.closestBatches++;
+                if (ids.size() > st.largestBatch) st.largestBatch = ids.size();
+                parallelFor(ids.size(), [&](size_t i) {
+                    const uint32_t s = ids[i];
+                    YartRay shadow;
+                    if (integ.onClosest(s, batch[i], hits[i], &shadow)) { ray[s] = shadow; state[s] = kShadow; }
+                    else state[s] = kIdle;
+                });
+            }
+
+            collect(state, kShadow, ids);
+            if (!ids.empty()) {
+                gather(ids, ray, batch);
+                occ.resize(ids.size());
+                check(engine_.any(engine_.accel, batch.data(), batch.size(), occ.data(), engine_.flags));
+                st.shadowRays += ids.size();
+                st.shadowBatches++;
+                parallelFor(ids.size(), [&](size_t i) {
+                    const uint32_t s = ids[i];
+                    YartRay next;
+                    if (integ.onShadow(s, occ[i] != 0, &next)) { ray[s] = next; state[s] = kClosest; }
+                    else state[s] = kIdle;
+                });
+            }
+
+            bool allDone = true;
+            for (size_t s = 0; s < nSlots_ && allDone; ++s) allDone = state[s] == kDone;
+            if (allDone) return st;
+        }
+    }
+
+private:
+    static void collect(const std::vector<uint8_t>& state, uint8_t want, std::vector<uint32_t>& ids)
+    {
+        ids.clear();
+        for (size_t s = 0; s < state.size(); ++s)
+            if (state[s] == want) ids.push_back(static_cast<uint32_t>(s));
+    }
+    static void gather(const std::vector<uint32_t>& ids, const std::vector<YartRay>& ray, std::vector<YartRay>& batch)
+    {
+        batch.resize(ids.size());
+        for (size_t i = 0; i < ids.size(); ++i) batch[i] = ray[ids[i]];
+    }
+    static void check(int st)
+    {
+        if (st != YART_OK) throw std::runtime_error("yart_amd::WavefrontDriver: engine call failed, status " + std::to_string(st));
+    }
+    template <class F>
+    void parallelFor(size_t n, F&& f) const
+    {
+        if (nThreads_ <= 1 || n < 64) { for (size_t i = 0; i < n; ++i) f(i); return; }
+        std::atomic<size_t> next{ 0 };
+        const size_t chunk = n / (static_cast<size_t>(nThreads_) * 8) + 1;
+        auto body = [&]() {
+            for (;;) {
+                const size_t b = next.fetch_add(chunk);
+                if (b >= n) return;
+                const size_t e = b + chunk < n ? b + chunk : n;
+                for (size_t i = b; i < e; ++i) f(i);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nThreads_; ++t) pool.emplace_back(body);
+        body();
+        for (auto& t : pool) t.join();
+    }
+
+    Engine engine_;
+    size_t nSlots_;
+    int nThreads_;
+};
+
+} // namespace yart_amd
