@@ -75,15 +75,22 @@ def main():
         log("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path)")
-    torch.cuda.set_device(local_rank)
+    n_dev = torch.cuda.device_count()
+    own_gpu = n_dev >= world                  # one GPU per rank: RCCL; ranks sharing a GPU (rehearsal on a one-GPU box): gloo
+    device = local_rank if own_gpu else local_rank % n_dev
+    torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if own_gpu:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            log("warning: %d ranks on %d GPU(s): rehearsal over gloo, ranks share a device" % (world, n_dev))
+            dist.init_process_group("gloo")
 
     t0 = time.time()
     verts, tris, sph = scenes.random_soup(args.tris, args.spheres, s=args.s, seed=42)
     rays = scenes.random_rays(args.rays, seed=7 + rank)
     t1 = time.time()
-    acc = api.Accel(verts, tris, sph, device=local_rank)
+    acc = api.Accel(verts, tris, sph, device=device)
     t2 = time.time()
     if rank == 0:
         log("scene: %d tris, %d spheres, %d nodes, depth %d, %.1f MB in HBM (gen %.1fs, build+upload %.1fs)"
@@ -128,7 +135,7 @@ def main():
     prof = acc.profile_read()
     acc.profile(False)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if own_gpu else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
