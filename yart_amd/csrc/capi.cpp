@@ -67,7 +67,7 @@ struct YartAccel {
     // scheduling knobs of the persistent kernel (YART_REFILL_MIN / YART_NODE_MIN override)
     uint32_t refillMin = 16, nodeMin = 24;                    // reference-tree kernels
     uint32_t wideRefillMin = 16, wideNodeMin = 40, wideChunk = 64, wideBlocksPerCU = 0;   // wide-tree kernel
-    uint32_t sortOctShift = 0;
+    uint32_t sortOctShift = 0, sortGridBits = 7;      // 7: 24-bit keys = 3 radix passes; finer grids measured no better
     // Small host-buffer calls (the one-ray-per-call pattern of the reference's renderer,
     // src/renderer.cpp:59,104): a pool of { stream, pinned host block the kernels read and
     // write in place } so that such a call costs launches + one stream synchronise, no
@@ -165,7 +165,7 @@ int run(YartAccel* a, const Launch& L)
         perm = reinterpret_cast<uint32_t*>(static_cast<char*>(sortWs) + wsBytes);
         {
             ScopedSpan span(a, 0, L.stream);
-            e = yart::sortRays(reinterpret_cast<const float4*>(L.rays), n, a->sceneLo, a->sceneHi, a->sortOctShift, perm,
+            e = yart::sortRays(reinterpret_cast<const float4*>(L.rays), n, a->sceneLo, a->sceneHi, a->sortOctShift, a->sortGridBits, perm,
                                sortWs, wsBytes, L.stream);
         }
         if (e != hipSuccess) { (void)hipFreeAsync(sortWs, L.stream); return failHip(e, "sortRays"); }
@@ -262,6 +262,7 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
     if (const char* v = std::getenv("YART_WIDE_NODE_MIN")) a->wideNodeMin = static_cast<uint32_t>(std::atoi(v));
     if (a->wideNodeMin < 1) a->wideNodeMin = 1;
     if (a->wideNodeMin > 64) a->wideNodeMin = 64;
+    if (const char* v = std::getenv("YART_SORT_GRID_BITS")) a->sortGridBits = static_cast<uint32_t>(std::atoi(v));
     if (const char* v = std::getenv("YART_SORT_OCT_SHIFT")) a->sortOctShift = static_cast<uint32_t>(std::atoi(v));
     if (const char* v = std::getenv("YART_WIDE_BLOCKS_PER_CU")) a->wideBlocksPerCU = static_cast<uint32_t>(std::atoi(v));
     if (const char* v = std::getenv("YART_WIDE_CHUNK")) a->wideChunk = static_cast<uint32_t>(std::atoi(v));

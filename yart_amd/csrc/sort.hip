@@ -1,7 +1,7 @@
 // sort.hip -- coherence sort of a ray batch (YART_SORT_RAYS).
 //
-// Key = 27-bit Morton code of the ray origin quantised to 512^3 cells of the scene
-// bounds, followed by the 3-bit direction octant; rays that start in the same cell
+// Key = Morton code of the ray origin quantised to (2^gridBits)^3 cells of the scene
+// bounds (default 7 bits per axis: 24-bit key, three radix passes), followed by the 3-bit direction octant; rays that start in the same cell
 // and head the same way become neighbours, so the lanes of a wave walk the same
 // upper tree levels and touch the same cache lines.  The reference has no
 // counterpart: its renderer issues one ray at a time (src/renderer.cpp:59,104).
@@ -28,16 +28,16 @@ __device__ __forceinline__ uint32_t spread3(uint32_t v)      // 9 bits -> every 
 __global__ void __launch_bounds__(256) rayKeys(const float4* __restrict__ rays, uint32_t n,
                                                float lox, float loy, float loz,
                                                float sx, float sy, float sz,
-                                               uint32_t octShift,
+                                               uint32_t octShift, float cellMax,
                                                uint32_t* __restrict__ keys, uint32_t* __restrict__ ids)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const float4 o = rays[(size_t)i * 2];
     const float4 d = rays[(size_t)i * 2 + 1];
-    const float fx = fminf(fmaxf((o.x - lox) * sx, 0.0f), 511.0f);
-    const float fy = fminf(fmaxf((o.y - loy) * sy, 0.0f), 511.0f);
-    const float fz = fminf(fmaxf((o.z - loz) * sz, 0.0f), 511.0f);
+    const float fx = fminf(fmaxf((o.x - lox) * sx, 0.0f), cellMax);
+    const float fy = fminf(fmaxf((o.y - loy) * sy, 0.0f), cellMax);
+    const float fz = fminf(fmaxf((o.z - loz) * sz, 0.0f), cellMax);
     const uint32_t m = spread3((uint32_t)fx) | (spread3((uint32_t)fy) << 1) | (spread3((uint32_t)fz) << 2);
     const uint32_t oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
     // the octant sits above the lowest `octShift` Morton bits: rays of one (2^-(9-octShift/3))^3
@@ -64,7 +64,7 @@ size_t sortWorkspaceBytes(uint32_t n)
 }
 
 hipError_t sortRays(const float4* rays, uint32_t n, const float lo[3], const float hi[3], uint32_t octShift,
-                    uint32_t* perm, void* workspace, size_t workspaceBytes, hipStream_t stream)
+                    uint32_t gridBits, uint32_t* perm, void* workspace, size_t workspaceBytes, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
     const size_t seg = alignUp((size_t)n * 4);
@@ -74,16 +74,21 @@ hipError_t sortRays(const float4* rays, uint32_t n, const float lo[3], const flo
     uint32_t* idsIn = reinterpret_cast<uint32_t*>(w + 2 * seg);
     void* temp = w + 3 * seg;
     size_t tempBytes = workspaceBytes - 3 * seg;
+    if (gridBits < 1) gridBits = 1;
+    if (gridBits > 9) gridBits = 9;
+    const float cells = static_cast<float>(1u << gridBits);
+    const int keyBits = static_cast<int>(3 * gridBits + 3);
+    if (octShift > 3 * gridBits) octShift = 3 * gridBits;
     float s[3];
     for (int a = 0; a < 3; ++a) {
         const float ext = hi[a] - lo[a];
-        s[a] = (ext > 0.0f && ext < 3.0e38f) ? 512.0f / ext : 0.0f;
+        s[a] = (ext > 0.0f && ext < 3.0e38f) ? cells / ext : 0.0f;
     }
     hipLaunchKernelGGL(rayKeys, dim3((n + 255) / 256), dim3(256), 0, stream, rays, n,
-                       lo[0], lo[1], lo[2], s[0], s[1], s[2], octShift > 27 ? 27u : octShift, keysIn, idsIn);
+                       lo[0], lo[1], lo[2], s[0], s[1], s[2], octShift, cells - 1.0f, keysIn, idsIn);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, keysIn, keysOut, idsIn, perm, (int)n, 0, 30, stream);
+    return hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, keysIn, keysOut, idsIn, perm, (int)n, 0, keyBits, stream);
 }
 
 } // namespace yart

@@ -70,7 +70,7 @@ hipError_t launchTrace(const TraceParams& P, int prim, bool any, bool prune, boo
 // the ray origin inside [lo,hi] plus the direction octant.  `keys` and `tmp` are
 // n-element scratch arrays.
 hipError_t sortRays(const float4* rays, uint32_t n, const float lo[3], const float hi[3], uint32_t octShift,
-                    uint32_t* perm, void* workspace, size_t workspaceBytes, hipStream_t stream);
+                    uint32_t gridBits, uint32_t* perm, void* workspace, size_t workspaceBytes, hipStream_t stream);
 size_t sortWorkspaceBytes(uint32_t n);
 
 } // namespace yart
