@@ -72,7 +72,8 @@ struct YartAccel {
     // src/renderer.cpp:59,104): a pool of { stream, pinned host block the kernels read and
     // write in place } so that such a call costs launches + one stream synchronise, no
     // allocation and no copy.  A context is taken for the duration of one call.
-    struct Staging { hipStream_t stream = nullptr; void* host = nullptr; void* dev = nullptr; };
+    struct Staging { hipStream_t stream = nullptr; void* host = nullptr; void* dev = nullptr;
+                     void* big = nullptr; size_t bigBytes = 0; };     // + a device block kept for larger batches
     std::mutex stagingMutex;
     std::vector<Staging> stagingFree;
 
@@ -345,6 +346,7 @@ void yart_accel_destroy(YartAccel* a)
         (void)hipFree(a->dWideRowsBC);
         for (auto& c : a->stagingFree) {
             (void)hipHostFree(c.host);
+            (void)hipFree(c.big);
             (void)hipStreamDestroy(c.stream);
         }
     }
@@ -375,11 +377,12 @@ int yart_intersect_any_counted_dev(YartAccel* accel, const YartRay* d_rays, size
     return run(accel, Launch{ true, true, d_rays, n, nullptr, d_occluded, d_counts, flags, static_cast<hipStream_t>(stream) });
 }
 
-// Batches of up to kStagingRays rays go through a pooled pinned block (see YartAccel::Staging).
+// Host-buffer calls take a pooled context (see YartAccel::Staging): batches of up to kStagingRays
+// rays go through its pinned block, larger ones through its device block.
 constexpr size_t kStagingRays = 4096;
 constexpr size_t kStagingBytes = kStagingRays * (sizeof(YartRay) + sizeof(YartHit));
 
-static int smallHostCall(YartAccel* accel, const YartRay* rays, size_t n, YartHit* hits, uint8_t* occluded, unsigned flags)
+static int pooledHostCall(YartAccel* accel, const YartRay* rays, size_t n, YartHit* hits, uint8_t* occluded, unsigned flags)
 {
     YartAccel::Staging c;
     {
@@ -397,24 +400,51 @@ static int smallHostCall(YartAccel* accel, const YartRay* rays, size_t n, YartHi
             return fail(YART_ERR_OUT_OF_MEMORY, std::string("pinned staging block: ") + hipGetErrorString(e));
         }
     }
-    std::memcpy(c.host, rays, n * sizeof(YartRay));
-    char* dOut = static_cast<char*>(c.dev) + kStagingRays * sizeof(YartRay);
-    const char* hOut = static_cast<char*>(c.host) + kStagingRays * sizeof(YartRay);
-    // a handful of rays cannot fill persistent workgroups: plain grid.  The rays are in host
-    // memory here, so whether any of them needs the fix-up launches is known up front.
-    bool regular = true;
-    for (size_t i = 0; i < n && regular; ++i)
-        regular = yart::regularRay(rays[i].ox, rays[i].oy, rays[i].oz, rays[i].tmin, rays[i].dx, rays[i].dy, rays[i].dz, rays[i].tmax);
-    const unsigned f = flags | YART_STATIC_LAUNCH | (regular ? YART_RAYS_REGULAR : YART_REFERENCE_TREE);
-    int st = hits ? yart_intersect_closest_dev(accel, static_cast<YartRay*>(c.dev), n, reinterpret_cast<YartHit*>(dOut), f, c.stream)
+    int st = YART_OK;
+    const size_t outBytes = hits ? n * sizeof(YartHit) : n;
+    if (n <= kStagingRays) {
+        // the kernels read and write the pinned block in place: launches + one synchronise
+        std::memcpy(c.host, rays, n * sizeof(YartRay));
+        char* dOut = static_cast<char*>(c.dev) + kStagingRays * sizeof(YartRay);
+        const char* hOut = static_cast<char*>(c.host) + kStagingRays * sizeof(YartRay);
+        // a handful of rays cannot fill persistent workgroups: plain grid.  The rays are in host
+        // memory here, so whether any of them needs the fix-up launches is known up front.
+        bool regular = true;
+        for (size_t i = 0; i < n && regular; ++i)
+            regular = yart::regularRay(rays[i].ox, rays[i].oy, rays[i].oz, rays[i].tmin, rays[i].dx, rays[i].dy, rays[i].dz, rays[i].tmax);
+        const unsigned f = flags | YART_STATIC_LAUNCH | (regular ? YART_RAYS_REGULAR : YART_REFERENCE_TREE);
+        st = hits ? yart_intersect_closest_dev(accel, static_cast<YartRay*>(c.dev), n, reinterpret_cast<YartHit*>(dOut), f, c.stream)
                   : yart_intersect_any_dev(accel, static_cast<YartRay*>(c.dev), n, reinterpret_cast<uint8_t*>(dOut), f, c.stream);
-    if (st == YART_OK) {
-        const hipError_t e = hipStreamSynchronize(c.stream);
-        if (e != hipSuccess) st = failHip(e, "hipStreamSynchronize");
-    }
-    if (st == YART_OK) {
-        if (hits) std::memcpy(hits, hOut, n * sizeof(YartHit));
-        else std::memcpy(occluded, hOut, n);
+        if (st == YART_OK) {
+            const hipError_t e = hipStreamSynchronize(c.stream);
+            if (e != hipSuccess) st = failHip(e, "hipStreamSynchronize");
+        }
+        if (st == YART_OK) std::memcpy(hits ? static_cast<void*>(hits) : static_cast<void*>(occluded), hOut, outBytes);
+    } else {
+        // larger batches: a device block kept with the context (grown on demand), copies on its stream
+        const size_t rayBytes = (n * sizeof(YartRay) + 255) & ~size_t(255);
+        const size_t need = rayBytes + outBytes;
+        if (need > c.bigBytes) {
+            (void)hipFree(c.big);
+            c.big = nullptr;
+            c.bigBytes = 0;
+            const hipError_t e = hipMalloc(&c.big, need);
+            if (e != hipSuccess) st = fail(YART_ERR_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e));
+            else c.bigBytes = need;
+        }
+        if (st == YART_OK) {
+            char* dOut = static_cast<char*>(c.big) + rayBytes;
+            hipError_t e = hipMemcpyAsync(c.big, rays, n * sizeof(YartRay), hipMemcpyHostToDevice, c.stream);
+            if (e != hipSuccess) st = failHip(e, "hipMemcpy H2D");
+            if (st == YART_OK)
+                st = hits ? yart_intersect_closest_dev(accel, static_cast<YartRay*>(c.big), n, reinterpret_cast<YartHit*>(dOut), flags, c.stream)
+                          : yart_intersect_any_dev(accel, static_cast<YartRay*>(c.big), n, reinterpret_cast<uint8_t*>(dOut), flags, c.stream);
+            if (st == YART_OK) {
+                e = hipMemcpyAsync(hits ? static_cast<void*>(hits) : static_cast<void*>(occluded), dOut, outBytes, hipMemcpyDeviceToHost, c.stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+                if (e != hipSuccess) st = failHip(e, "hipMemcpy D2H");
+            }
+        }
     }
     std::lock_guard<std::mutex> lock(accel->stagingMutex);
     accel->stagingFree.push_back(c);
@@ -428,26 +458,7 @@ static int hostCall(YartAccel* accel, const YartRay* rays, size_t n, YartHit* hi
     if (!rays || (!hits && !occluded)) return fail(YART_ERR_INVALID_ARGUMENT, "null ray / result pointer");
     DeviceGuard guard(accel->device);
     if (!guard.ok) return fail(YART_ERR_NO_DEVICE, "hipSetDevice failed");
-    if (n <= kStagingRays) return smallHostCall(accel, rays, n, hits, occluded, flags);
-    void* dRays = nullptr;
-    void* dOut = nullptr;
-    const size_t outBytes = hits ? n * sizeof(YartHit) : n;
-    hipError_t e = hipMalloc(&dRays, n * sizeof(YartRay));
-    if (e == hipSuccess) e = hipMalloc(&dOut, outBytes);
-    int st = YART_OK;
-    if (e != hipSuccess) st = fail(YART_ERR_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e));
-    if (st == YART_OK && (e = hipMemcpy(dRays, rays, n * sizeof(YartRay), hipMemcpyHostToDevice)) != hipSuccess)
-        st = failHip(e, "hipMemcpy H2D");
-    if (st == YART_OK) {
-        st = hits ? yart_intersect_closest_dev(accel, static_cast<YartRay*>(dRays), n, static_cast<YartHit*>(dOut), flags, nullptr)
-                  : yart_intersect_any_dev(accel, static_cast<YartRay*>(dRays), n, static_cast<uint8_t*>(dOut), flags, nullptr);
-    }
-    if (st == YART_OK && (e = hipMemcpy(hits ? static_cast<void*>(hits) : static_cast<void*>(occluded), dOut, outBytes,
-                                        hipMemcpyDeviceToHost)) != hipSuccess)
-        st = failHip(e, "hipMemcpy D2H");
-    (void)hipFree(dRays);
-    (void)hipFree(dOut);
-    return st;
+    return pooledHostCall(accel, rays, n, hits, occluded, flags);
 }
 
 int yart_intersect_closest(YartAccel* accel, const YartRay* rays, size_t n, YartHit* hits, unsigned flags)
