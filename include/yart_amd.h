@@ -195,6 +195,14 @@ int yart_build_host(const float* verts, size_t n_verts,
                     YartBvhNode* nodes_out, size_t* n_nodes,
                     YartTriAccel* triaccel_out);
 
+/* Host-only build of the engine's 4-wide tree (no HIP call; layout as yart_accel_get_wide).
+ * Call with NULL array outputs to query n_nodes / n_prims, then again with arrays of that
+ * size.  max_leaf in 1..8 (the accel uses 1).  Used by CPU-side tests. */
+int yart_build_wide_host(const float* verts, size_t n_verts, const int32_t* tris, size_t n_tris,
+                         const float* spheres, size_t n_spheres, int max_leaf,
+                         void* nodes_out, size_t* n_nodes, void* rows_a_out, void* rows_bc_out,
+                         size_t* n_prims, int* depth);
+
 /* Per-kernel timing (no counterpart in the reference, which only has a wall-clock
  * Timer around the whole render, include/timer.h:6-26).  While enabled, every
  * intersect call brackets its launches with HIP events on the caller's stream, in three

@@ -36,7 +36,7 @@ EXPORTS = [
     "yart_accel_get_nodes", "yart_accel_get_triaccel", "yart_accel_depth",
     "yart_accel_device_bytes", "yart_build_host", "yart_status_string", "yart_last_error",
     "yart_accel_profile_enable", "yart_accel_profile_read",
-    "yart_accel_num_wide_nodes", "yart_accel_num_wide_prims", "yart_accel_wide_depth", "yart_accel_get_wide",
+    "yart_build_wide_host", "yart_accel_num_wide_nodes", "yart_accel_num_wide_prims", "yart_accel_wide_depth", "yart_accel_get_wide",
 ]
 
 _vp = ctypes.c_void_p
@@ -76,6 +76,8 @@ def lib():
     L.yart_accel_get_nodes.argtypes = [_vp, _vp]
     L.yart_accel_get_triaccel.argtypes = [_vp, _vp]
     L.yart_build_host.argtypes = [_vp, _sz, _vp, _sz, _vp, ctypes.POINTER(_sz), _vp]
+    L.yart_build_wide_host.argtypes = [_vp, _sz, _vp, _sz, _vp, _sz, ctypes.c_int, _vp, ctypes.POINTER(_sz), _vp, _vp,
+                                       ctypes.POINTER(_sz), ctypes.POINTER(ctypes.c_int)]
     L.yart_accel_profile_enable.argtypes = [_vp, ctypes.c_int]
     L.yart_accel_profile_read.argtypes = [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                           ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
@@ -115,6 +117,20 @@ def build_host(verts, tris):
     ta = np.zeros(len(tris), TRIACCEL_DTYPE)
     _check(L.yart_build_host(_p(verts), len(verts), _p(tris), len(tris), _p(nodes), ctypes.byref(n), _p(ta)))
     return nodes, ta
+
+
+def build_wide_host(verts, tris, spheres=None, max_leaf=1):
+    """Host-only build of the 4-wide tree (no GPU needed) -> nodes uint32 [n,16], rowsA [p,4], rowsBC [p,8], depth."""
+    L = lib()
+    verts, tris, spheres = _scene_arrays(verts, tris, spheres)
+    nn, npr, depth = _sz(0), _sz(0), ctypes.c_int(0)
+    args = (_p(verts), len(verts), _p(tris), len(tris), _p(spheres), len(spheres), int(max_leaf))
+    _check(L.yart_build_wide_host(*args, None, ctypes.byref(nn), None, None, ctypes.byref(npr), ctypes.byref(depth)))
+    nodes = np.zeros((nn.value, 16), np.uint32)
+    rows_a = np.zeros((npr.value, 4), np.float32)
+    rows_bc = np.zeros((npr.value, 8), np.float32)
+    _check(L.yart_build_wide_host(*args, _p(nodes), ctypes.byref(nn), _p(rows_a), _p(rows_bc), ctypes.byref(npr), ctypes.byref(depth)))
+    return nodes, rows_a, rows_bc, depth.value
 
 
 class Accel:

@@ -519,6 +519,26 @@ int yart_build_host(const float* verts, size_t n_verts, const int32_t* tris, siz
     return YART_OK;
 }
 
+int yart_build_wide_host(const float* verts, size_t n_verts, const int32_t* tris, size_t n_tris,
+                         const float* spheres, size_t n_spheres, int max_leaf,
+                         void* nodes_out, size_t* n_nodes, void* rows_a_out, void* rows_bc_out, size_t* n_prims,
+                         int* depth)
+{
+    yart::TriangleBvh tri;
+    yart::WideBvh wide;
+    std::string err;
+    int st = yart::buildTriangleBvh(verts, n_verts, tris, n_tris, tri, err);
+    if (st == YART_OK) st = yart::buildWideBvh(verts, n_verts, tris, n_tris, tri, spheres, n_spheres, max_leaf, wide, err);
+    if (st != YART_OK) return fail(st, err);
+    if (n_nodes) *n_nodes = wide.nodes.size();
+    if (n_prims) *n_prims = wide.rowsA.size() / 4;
+    if (depth) *depth = wide.depth;
+    if (nodes_out) std::memcpy(nodes_out, wide.nodes.data(), wide.nodes.size() * sizeof(yart::WideNode));
+    if (rows_a_out) std::memcpy(rows_a_out, wide.rowsA.data(), wide.rowsA.size() * sizeof(float));
+    if (rows_bc_out) std::memcpy(rows_bc_out, wide.rowsBC.data(), wide.rowsBC.size() * sizeof(float));
+    return YART_OK;
+}
+
 int yart_accel_profile_enable(YartAccel* a, int enable)
 {
     if (!a) return fail(YART_ERR_INVALID_ARGUMENT, "null accel");
