@@ -6,6 +6,9 @@
 #include "bvh_build.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -237,8 +240,12 @@ int buildTriangleBvh(const float* verts, size_t nVerts, const int32_t* tris, siz
         p.id = static_cast<uint32_t>(i);
     }
 
+    const bool timing = std::getenv("YART_BUILD_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     FlatTree t;
     buildFlat(prims, kLeafThreshold, t);
+    if (timing) fprintf(stderr, "reference tree: partition build %.2fs\n", now() - t0);
     if (t.depth > kMaxDepth) {
         err = "triangle BVH deeper than 64 levels";
         return YART_ERR_TREE_TOO_DEEP;

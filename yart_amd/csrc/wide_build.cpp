@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <condition_variable>
 #include <cstdlib>
@@ -439,11 +441,16 @@ int buildWideBvh(const float* verts, size_t nVerts, const int32_t* tris, size_t 
         return false;
     }), prims.end());
 
+    const bool timing = std::getenv("YART_BUILD_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (int attempt = 0; attempt < 2; ++attempt) {
+        const double t0 = now();
         BinaryBuilder b(prims, maxLeaf, attempt == 1);
         if (!prims.empty()) b.run();
+        const double t1 = now();
         Emitter e(b.nodes(), prims, tri, spheres, out);
         e.run();
+        if (timing) fprintf(stderr, "wide build: binary SAH %.2fs, collapse+emit %.2fs (%zu nodes, depth %d)\n", t1 - t0, now() - t1, out.nodes.size(), out.depth);
         if (e.tooManyPrims) {
             err = "wide BVH: more than 2^27 - 1 primitives";
             return YART_ERR_INVALID_ARGUMENT;
