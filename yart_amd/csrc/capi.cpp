@@ -56,7 +56,8 @@ struct YartAccel {
     void* dWideRowsA = nullptr;
     void* dWideRowsBC = nullptr;
     bool hasWide = false;
-    yart::WideBvh wide;               // host copy kept for yart_accel_get_wide (parity dumps)
+    size_t wideNodes = 0, widePrims = 0;   // array sizes; the device copy is the only one kept
+    int wideDepth = 0;
     size_t deviceBytes = 0;
     std::atomic<unsigned> nextCounter{ 0 };
     // per-kernel timing (yart_accel_profile_*): kind 0 = sort, 1 = sphere tree, 2 = triangle tree
@@ -274,13 +275,14 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
     int st = yart::buildTriangleBvh(verts, n_verts, tris, n_tris, a->tri, err);
     yart::SphereBvh sph;
     if (st == YART_OK) st = yart::buildSphereBvh(spheres, n_spheres, sph, err);
+    yart::WideBvh wide;
     const char* noWide = std::getenv("YART_NO_WIDE");
     const bool wantWide = !(noWide && noWide[0] == '1');
     if (st == YART_OK && wantWide) {
         int maxLeaf = 1;            // measured best on MI355X (tools/exp_wide.py): the box of a single primitive is a
                                     // cheaper rejection than its plane row, and rows of different leaves are not tested
         if (const char* v = std::getenv("YART_WIDE_LEAF")) maxLeaf = std::atoi(v);
-        st = yart::buildWideBvh(verts, n_verts, tris, n_tris, a->tri, spheres, n_spheres, maxLeaf, a->wide, err);
+        st = yart::buildWideBvh(verts, n_verts, tris, n_tris, a->tri, spheres, n_spheres, maxLeaf, wide, err);
     }
     if (st != YART_OK) { delete a; return fail(st, err); }
     a->numTriPairs = a->tri.pairs.size();
@@ -311,10 +313,13 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
     if (st == YART_OK) st = upload(&a->dSphRecs, sph.records.data(), sph.records.size() * sizeof(float), a->deviceBytes);
     if (st == YART_OK) st = upload(&a->dSphIndex, sph.index.data(), sph.index.size() * sizeof(uint32_t), a->deviceBytes);
     if (st == YART_OK && wantWide) {
-        st = upload(&a->dWideNodes, a->wide.nodes.data(), a->wide.nodes.size() * sizeof(yart::WideNode), a->deviceBytes);
-        if (st == YART_OK) st = upload(&a->dWideRowsA, a->wide.rowsA.data(), a->wide.rowsA.size() * sizeof(float), a->deviceBytes);
-        if (st == YART_OK) st = upload(&a->dWideRowsBC, a->wide.rowsBC.data(), a->wide.rowsBC.size() * sizeof(float), a->deviceBytes);
+        st = upload(&a->dWideNodes, wide.nodes.data(), wide.nodes.size() * sizeof(yart::WideNode), a->deviceBytes);
+        if (st == YART_OK) st = upload(&a->dWideRowsA, wide.rowsA.data(), wide.rowsA.size() * sizeof(float), a->deviceBytes);
+        if (st == YART_OK) st = upload(&a->dWideRowsBC, wide.rowsBC.data(), wide.rowsBC.size() * sizeof(float), a->deviceBytes);
         a->hasWide = (st == YART_OK);
+        a->wideNodes = wide.nodes.size();
+        a->widePrims = wide.rowsA.size() / 4;
+        a->wideDepth = wide.depth;
     }
     if (st == YART_OK) {
         hipError_t e = hipMalloc(&a->dCounters, 256 * kCounterSlots);
@@ -493,16 +498,20 @@ int yart_accel_get_triaccel(const YartAccel* a, YartTriAccel* out)
     return YART_OK;
 }
 
-size_t yart_accel_num_wide_nodes(const YartAccel* a) { return a ? a->wide.nodes.size() : 0; }
-size_t yart_accel_num_wide_prims(const YartAccel* a) { return a ? a->wide.rowsA.size() / 4 : 0; }
-int yart_accel_wide_depth(const YartAccel* a) { return a ? a->wide.depth : 0; }
+size_t yart_accel_num_wide_nodes(const YartAccel* a) { return a ? a->wideNodes : 0; }
+size_t yart_accel_num_wide_prims(const YartAccel* a) { return a ? a->widePrims : 0; }
+int yart_accel_wide_depth(const YartAccel* a) { return a ? a->wideDepth : 0; }
 
 int yart_accel_get_wide(const YartAccel* a, void* nodes_out, void* rows_a_out, void* rows_bc_out)
 {
     if (!a) return fail(YART_ERR_INVALID_ARGUMENT, "null argument");
-    if (nodes_out) std::memcpy(nodes_out, a->wide.nodes.data(), a->wide.nodes.size() * sizeof(yart::WideNode));
-    if (rows_a_out) std::memcpy(rows_a_out, a->wide.rowsA.data(), a->wide.rowsA.size() * sizeof(float));
-    if (rows_bc_out) std::memcpy(rows_bc_out, a->wide.rowsBC.data(), a->wide.rowsBC.size() * sizeof(float));
+    if (!a->hasWide) return fail(YART_ERR_INVALID_ARGUMENT, "accel was created without the wide tree (YART_NO_WIDE)");
+    DeviceGuard guard(a->device);
+    hipError_t e = hipSuccess;
+    if (nodes_out && a->wideNodes) e = hipMemcpy(nodes_out, a->dWideNodes, a->wideNodes * sizeof(yart::WideNode), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && rows_a_out && a->widePrims) e = hipMemcpy(rows_a_out, a->dWideRowsA, a->widePrims * 16, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && rows_bc_out && a->widePrims) e = hipMemcpy(rows_bc_out, a->dWideRowsBC, a->widePrims * 32, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return failHip(e, "hipMemcpy D2H");
     return YART_OK;
 }
 
