@@ -115,7 +115,8 @@ def test_walk_matches_reference(golden, max_leaf):
     assert np.array_equal(occ, g["occluded"][ms])
 
 
-@pytest.mark.parametrize("n_tris,n_sph,s", [(0, 0, 0.1), (1, 0, 0.1), (0, 1, 0.1), (5, 3, 0.2), (3000, 300, 0.05), (20000, 0, 0.01)])
+@pytest.mark.parametrize("n_tris,n_sph,s", [(0, 0, 0.1), (1, 0, 0.1), (0, 1, 0.1), (5, 3, 0.2), (3000, 300, 0.05), (20000, 0, 0.01),
+                                              (70000, 3000, 0.01)])      # > 32768 primitives: the threaded build / emission
 def test_seeded_scenes_against_reference_rule(n_tris, n_sph, s):
     v, t, sph = scenes.random_soup(n_tris, n_sph, s=s, seed=n_tris + 7 * n_sph + 1)
     rays = scenes.random_rays(20000, seed=3)

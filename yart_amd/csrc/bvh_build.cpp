@@ -246,6 +246,7 @@ int buildTriangleBvh(const float* verts, size_t nVerts, const int32_t* tris, siz
     FlatTree t;
     buildFlat(prims, kLeafThreshold, t);
     if (timing) fprintf(stderr, "reference tree: partition build %.2fs\n", now() - t0);
+    const double t1 = now();
     if (t.depth > kMaxDepth) {
         err = "triangle BVH deeper than 64 levels";
         return YART_ERR_TREE_TOO_DEEP;
@@ -282,7 +283,9 @@ int buildTriangleBvh(const float* verts, size_t nVerts, const int32_t* tris, siz
         err = "too many BVH nodes";
         return YART_ERR_INVALID_ARGUMENT;
     }
+    const double t2 = now();
     emitPairs(t, slot, out.pairs);
+    if (timing) fprintf(stderr, "reference tree: leaf slots + node records + projection %.2fs, pair layout %.2fs\n", t2 - t1, now() - t2);
     return YART_OK;
 }
 

@@ -2,6 +2,7 @@
 // thread pool, collapse to four children per node, depth-first emission of 64-byte quantised nodes and
 // two-stage leaf rows.
 #include "wide_build.h"
+#include "task_pool.h"
 
 #include <algorithm>
 #include <atomic>
@@ -12,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -48,10 +50,18 @@ struct BPrim {
     uint32_t id;                // input triangle number, or kSphereId | sphere number
 };
 
-struct BNode {
+struct BNode {                          // trivially constructible: the pool below is never value-initialised
     Box box;
-    uint32_t left = 0, right = 0;       // interior (count == 0)
-    uint32_t begin = 0, count = 0;      // leaf: prims[begin, begin + count), one kind
+    uint32_t left, right;               // interior (count == 0)
+    uint32_t begin, count;              // leaf: prims[begin, begin + count), one kind
+    uint32_t span;                      // primitives below this node (any node)
+};
+
+struct BNodePool {                      // 2N+2 nodes of address space; only the pages a build touches are committed
+    std::unique_ptr<BNode[]> mem;
+    size_t used = 0;
+    const BNode& operator[](size_t i) const { return mem[i]; }
+    BNode& operator[](size_t i) { return mem[i]; }
 };
 
 class BinaryBuilder {
@@ -59,58 +69,24 @@ public:
     BinaryBuilder(std::vector<BPrim>& prims, int maxLeaf, bool medianOnly)
         : prims_(prims), maxLeaf_(maxLeaf), medianOnly_(medianOnly)
     {
-        nodes_.resize(std::max<size_t>(1, 2 * prims.size() + 2));
+        nodes_.mem.reset(new BNode[std::max<size_t>(1, 2 * prims.size() + 2)]);
+        nodes_[0] = BNode{};
     }
 
     void run()
     {
         next_ = 1;
-        pending_ = 1;
-        jobs_.push_back(Job{ 0u, 0u, static_cast<uint32_t>(prims_.size()) });
-        unsigned nThreads = std::thread::hardware_concurrency();
-        if (const char* v = std::getenv("OMP_NUM_THREADS")) { const int n = std::atoi(v); if (n > 0) nThreads = std::min<unsigned>(nThreads, n); }
-        nThreads = std::max(1u, std::min(nThreads, 32u));
+        unsigned nThreads = buildThreads();
         if (prims_.size() < kSpawnAbove) nThreads = 1;
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < nThreads; ++t) pool.emplace_back([this]() { work(); });
-        work();
-        for (auto& t : pool) t.join();
-        nodes_.resize(next_);
+        pool_.run(nThreads, Job{ 0u, 0u, static_cast<uint32_t>(prims_.size()) },
+                  [this](const Job& j) { build(j.node, j.begin, j.end, true); });
+        nodes_.used = next_;
     }
 
-    std::vector<BNode>& nodes() { return nodes_; }
+    BNodePool& nodes() { return nodes_; }
 
 private:
     struct Job { uint32_t node, begin, end; };
-
-    void work()
-    {
-        for (;;) {
-            Job j;
-            {
-                std::unique_lock<std::mutex> lock(m_);
-                cv_.wait(lock, [this]() { return !jobs_.empty() || pending_ == 0; });
-                if (jobs_.empty()) return;
-                j = jobs_.back();
-                jobs_.pop_back();
-            }
-            build(j.node, j.begin, j.end, true);
-            {
-                std::lock_guard<std::mutex> lock(m_);
-                if (--pending_ == 0) cv_.notify_all();
-            }
-        }
-    }
-
-    void spawn(uint32_t node, uint32_t begin, uint32_t end)
-    {
-        {
-            std::lock_guard<std::mutex> lock(m_);
-            ++pending_;
-            jobs_.push_back(Job{ node, begin, end });
-        }
-        cv_.notify_one();
-    }
 
     void build(uint32_t node, uint32_t begin, uint32_t end, bool maySpawn)
     {
@@ -124,6 +100,8 @@ private:
         BNode& n = nodes_[node];
         n.box = box;
         const uint32_t count = end - begin;
+        n.span = count;
+        n.left = n.right = n.begin = n.count = 0;
         uint32_t mid;
         if (count <= static_cast<uint32_t>(maxLeaf_)) {
             // a leaf holds one kind of primitive; a mixed remainder becomes two leaves
@@ -139,12 +117,11 @@ private:
             mid = split(begin, end, cbox);
         }
         const uint32_t l = next_.fetch_add(2);
-        nodes_[node].left = l;
-        nodes_[node].right = l + 1;
-        nodes_[node].count = 0;
+        n.left = l;
+        n.right = l + 1;
         if (maySpawn && count > kSpawnAbove) {
-            spawn(l, begin, mid);
-            spawn(l + 1, mid, end);
+            pool_.spawn(Job{ l, begin, mid });
+            pool_.spawn(Job{ l + 1, mid, end });
         } else {
             build(l, begin, mid, false);
             build(l + 1, mid, end, false);
@@ -222,55 +199,122 @@ private:
     }
 
     std::vector<BPrim>& prims_;
-    std::vector<BNode> nodes_;
+    BNodePool nodes_;
     std::atomic<uint32_t> next_{ 1 };
     int maxLeaf_;
     bool medianOnly_;
-    std::mutex m_;
-    std::condition_variable cv_;
-    std::vector<Job> jobs_;
-    int pending_ = 0;
+    TaskPool<Job> pool_;
 };
 
 float bitsFloat(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
+// Collapse + emission.  The top of the tree is emitted by one thread into segment 0; every binary
+// subtree below `jobSpan` primitives becomes a job emitted by the pool into a segment of its own
+// (local node / primitive numbers); the segments are then laid end to end, in depth-first order of
+// their roots, and their references rebased.
 class Emitter {
 public:
-    Emitter(const std::vector<BNode>& nodes, const std::vector<BPrim>& prims, const TriangleBvh& tri,
+    Emitter(const BNodePool& nodes, const std::vector<BPrim>& prims, const TriangleBvh& tri,
             const float* spheres, WideBvh& out)
         : nodes_(nodes), prims_(prims), tri_(tri), spheres_(spheres), out_(out) { }
 
     bool tooManyPrims = false;
 
-    void run()
+    void run(unsigned nThreads)
     {
         out_.nodes.clear();
         out_.rowsA.clear();
         out_.rowsBC.clear();
         out_.depth = 0;
         out_.numLeaves = 0;
-        size_t nTri = 0, nSph = 0;
-        for (const auto& p : prims_) ((p.id & kSphereId) ? nSph : nTri)++;
-        out_.rowsA.reserve((nTri + nSph) * 4);
-        out_.rowsBC.reserve((nTri + nSph) * 8);
-        out_.nodes.reserve(prims_.size() / 2 + 16);
+        if (prims_.size() > kWideMaxPrims) { tooManyPrims = true; return; }
         if (prims_.empty()) {
             out_.nodes.emplace_back();
             clear(out_.nodes[0]);
             out_.depth = 1;
             return;
         }
+        Segment top;
         if (nodes_[0].count > 0) {                       // the whole scene fits one leaf
-            out_.nodes.emplace_back();
-            const uint32_t ref = leaf(nodes_[0]);
-            setChildren(0, &nodes_[0].box, &ref, 1);
-            out_.depth = 1;
-            return;
+            top.nodes.emplace_back();
+            const uint32_t ref = leaf(nodes_[0], top);
+            setChildren(top.nodes[0], &nodes_[0].box, &ref, 1);
+            top.depth = 1;
+        } else {
+            jobSpan_ = std::max<uint32_t>(4096u, static_cast<uint32_t>(prims_.size() / (64u * std::max(1u, nThreads))));
+            if (nThreads <= 1) jobSpan_ = 0;             // everything in the top segment
+            emit(0, 1, top, &jobs_);
         }
-        emit(0, 1);
+        // jobs, in parallel
+        std::vector<Segment> segs(jobs_.size());
+        if (!jobs_.empty()) {
+            std::atomic<size_t> next{ 0 };
+            auto body = [&]() {
+                for (size_t j; (j = next.fetch_add(1)) < jobs_.size();) {
+                    emit(jobs_[j].bnode, jobs_[j].depth, segs[j], nullptr);
+                }
+            };
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < nThreads; ++t) pool.emplace_back(body);
+            body();
+            for (auto& t : pool) t.join();
+        }
+        // lay the segments end to end
+        std::vector<size_t> nodeBase(jobs_.size()), primBase(jobs_.size());
+        size_t nNodes = top.nodes.size(), nPrims = top.rowsA.size() / 4;
+        out_.depth = top.depth;
+        out_.numLeaves = top.leaves;
+        for (size_t j = 0; j < jobs_.size(); ++j) {
+            nodeBase[j] = nNodes;
+            primBase[j] = nPrims;
+            nNodes += segs[j].nodes.size();
+            nPrims += segs[j].rowsA.size() / 4;
+            out_.depth = std::max(out_.depth, segs[j].depth);
+            out_.numLeaves += segs[j].leaves;
+        }
+        if (nNodes >= (1ull << 31)) { tooManyPrims = true; return; }
+        for (size_t j = 0; j < jobs_.size(); ++j)        // the parents' references to the job roots
+            top.nodes[jobs_[j].parent].ref[jobs_[j].slot] = static_cast<uint32_t>(nodeBase[j]);
+        out_.nodes.resize(nNodes);
+        out_.rowsA.resize(nPrims * 4);
+        out_.rowsBC.resize(nPrims * 8);
+        auto place = [&](const Segment& sg, size_t nb, size_t pb) {
+            for (size_t i = 0; i < sg.nodes.size(); ++i) {
+                WideNode w = sg.nodes[i];
+                if (nb || pb) {
+                    for (auto& r : w.ref) {
+                        if (r == kWideNone) continue;
+                        if (r & kWideLeafBit) r = (r & 0xF8000000u) | static_cast<uint32_t>((r & 0x07FFFFFFu) + pb);
+                        else r = static_cast<uint32_t>(r + nb);
+                    }
+                }
+                out_.nodes[nb + i] = w;
+            }
+            if (!sg.rowsA.empty()) {
+                std::memcpy(out_.rowsA.data() + pb * 4, sg.rowsA.data(), sg.rowsA.size() * sizeof(float));
+                std::memcpy(out_.rowsBC.data() + pb * 8, sg.rowsBC.data(), sg.rowsBC.size() * sizeof(float));
+            }
+        };
+        place(top, 0, 0);
+        {
+            std::atomic<size_t> next{ 0 };
+            auto body = [&]() { for (size_t j; (j = next.fetch_add(1)) < segs.size();) place(segs[j], nodeBase[j], primBase[j]); };
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < nThreads && t < segs.size(); ++t) pool.emplace_back(body);
+            body();
+            for (auto& t : pool) t.join();
+        }
     }
 
 private:
+    struct Segment {
+        std::vector<WideNode> nodes;
+        std::vector<float> rowsA, rowsBC;
+        int depth = 0;
+        size_t leaves = 0;
+    };
+    struct Job { uint32_t bnode, parent; int slot, depth; };
+
     static void clear(WideNode& n)
     {
         std::memset(&n, 0, sizeof n);
@@ -283,9 +327,8 @@ private:
 
     // Quantise up to four child boxes on the grid of their union.  Containment is decided in double
     // on the float values the kernel will read: origin + qlo * scale <= lo and origin + qhi * scale >= hi.
-    void setChildren(uint32_t node, const Box* boxesIn, const uint32_t* refs, int n)
+    static void setChildren(WideNode& w, const Box* boxesIn, const uint32_t* refs, int n)
     {
-        WideNode& w = out_.nodes[node];
         clear(w);
         Box all, clamped[4];
         all.reset();
@@ -323,9 +366,11 @@ private:
         for (int i = 0; i < n; ++i) w.ref[i] = refs[i];
     }
 
-    uint32_t emit(uint32_t bnode, int depth)
+    // Emits the wide node rooted at binary node `bnode` (and everything below it) into `sg`; with
+    // `jobs` set, interior children of at most jobSpan_ primitives are recorded as jobs instead.
+    uint32_t emit(uint32_t bnode, int depth, Segment& sg, std::vector<Job>* jobs)
     {
-        out_.depth = std::max(out_.depth, depth);
+        sg.depth = std::max(sg.depth, depth);
         uint32_t kids[4] = { nodes_[bnode].left, nodes_[bnode].right, 0, 0 };
         int n = 2;
         while (n < 4) {                                  // open the largest interior child
@@ -341,23 +386,26 @@ private:
             kids[best] = nodes_[open].left;
             kids[n++] = nodes_[open].right;
         }
-        const uint32_t idx = static_cast<uint32_t>(out_.nodes.size());
-        out_.nodes.emplace_back();
+        const uint32_t idx = static_cast<uint32_t>(sg.nodes.size());
+        sg.nodes.emplace_back();
         Box boxes[4];
         uint32_t refs[4];
         for (int i = 0; i < n; ++i) {
             const BNode& c = nodes_[kids[i]];
             boxes[i] = c.box;
-            refs[i] = (c.count > 0) ? leaf(c) : emit(kids[i], depth + 1);
+            if (c.count > 0) refs[i] = leaf(c, sg);
+            else if (jobs && c.span <= jobSpan_) {
+                jobs->push_back(Job{ kids[i], idx, i, depth + 1 });
+                refs[i] = 0u;                            // patched when the segments are laid out
+            } else refs[i] = emit(kids[i], depth + 1, sg, jobs);
         }
-        setChildren(idx, boxes, refs, n);
+        setChildren(sg.nodes[idx], boxes, refs, n);
         return idx;
     }
 
-    uint32_t leaf(const BNode& n)
+    uint32_t leaf(const BNode& n, Segment& sg)
     {
-        const size_t first = out_.rowsA.size() / 4;
-        if (first + n.count > kWideMaxPrims) { tooManyPrims = true; return kWideNone; }
+        const size_t first = sg.rowsA.size() / 4;
         const uint32_t cnt = n.count;
         const bool sph = (prims_[n.begin].id & kSphereId) != 0;
         uint32_t ids[kWideMaxLeaf];
@@ -366,11 +414,11 @@ private:
             ids[i] = sph ? (id & ~kSphereId) : tri_.slotOfInput[id];
         }
         std::sort(ids, ids + cnt);                       // in-leaf test order: lowest slot / sphere number first
-        out_.rowsA.resize((first + cnt) * 4, 0.0f);
-        out_.rowsBC.resize((first + cnt) * 8, 0.0f);
+        sg.rowsA.resize((first + cnt) * 4, 0.0f);
+        sg.rowsBC.resize((first + cnt) * 8, 0.0f);
         for (uint32_t i = 0; i < cnt; ++i) {
-            float* A = out_.rowsA.data() + (first + i) * 4;
-            float* B = out_.rowsBC.data() + (first + i) * 8;
+            float* A = sg.rowsA.data() + (first + i) * 4;
+            float* B = sg.rowsBC.data() + (first + i) * 8;
             float* C = B + 4;
             if (sph) {
                 std::memcpy(A, spheres_ + static_cast<size_t>(ids[i]) * 4, 16);
@@ -382,15 +430,17 @@ private:
                 C[0] = ta.c_u; C[1] = ta.c_v; C[2] = ta.c_d;
             }
         }
-        ++out_.numLeaves;
+        ++sg.leaves;
         return kWideLeafBit | (sph ? kWideSphereBit : 0u) | ((cnt - 1) << 27) | static_cast<uint32_t>(first);
     }
 
-    const std::vector<BNode>& nodes_;
+    const BNodePool& nodes_;
     const std::vector<BPrim>& prims_;
     const TriangleBvh& tri_;
     const float* spheres_;
     WideBvh& out_;
+    std::vector<Job> jobs_;
+    uint32_t jobSpan_ = 0;
 };
 
 } // namespace
@@ -449,7 +499,7 @@ int buildWideBvh(const float* verts, size_t nVerts, const int32_t* tris, size_t 
         if (!prims.empty()) b.run();
         const double t1 = now();
         Emitter e(b.nodes(), prims, tri, spheres, out);
-        e.run();
+        e.run(prims.size() < kSpawnAbove ? 1u : buildThreads());
         if (timing) fprintf(stderr, "wide build: binary SAH %.2fs, collapse+emit %.2fs (%zu nodes, depth %d)\n", t1 - t0, now() - t1, out.nodes.size(), out.depth);
         if (e.tooManyPrims) {
             err = "wide BVH: more than 2^27 - 1 primitives";
