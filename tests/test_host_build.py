@@ -35,8 +35,9 @@ def test_builder_matches_reference_golden(golden):
     assert ta.tobytes() == golden["triaccel"].tobytes()
 
 
-@pytest.mark.parametrize("n", [0, 1, 7, 8, 9, 63, 64, 1000])
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 9, 63, 64, 1000, 70001])
 def test_builder_matches_oracle_on_ragged_sizes(n):
+    """70001 is above the size at which the builder hands ranges to its thread pool."""
     from oracle import oracle as orc
     v, t, s = scenes.random_soup(n, 0, s=0.1, seed=n + 1, tris_per_mesh=5)
     nodes, ta = api.build_host(v, t)

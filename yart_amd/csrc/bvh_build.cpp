@@ -4,6 +4,7 @@
 // exactly as the reference's C++ expression does, so that the node and
 // TriAccel arrays are bit-identical to the reference's.
 #include "bvh_build.h"
+#include "task_pool.h"
 
 #include <algorithm>
 #include <chrono>
@@ -12,6 +13,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <memory>
 
 namespace yart {
 namespace {
@@ -54,8 +56,6 @@ struct Prim {           // what the reference keeps per triangle while building 
     uint32_t id;        // index into the caller's primitive array
 };
 
-struct Task { uint32_t begin, end; int32_t parent; int depth; };
-
 // Partition step of the reference builder (src/bvhaccel.cpp:125-143): midpoint of
 // the node bounds on the widest axis (computed in double from a float sum),
 // std::partition by centre < midpoint, std::nth_element median when one side is
@@ -85,36 +85,90 @@ struct FlatTree {
     int depth = 0;
 };
 
-// Top-down build with an explicit stack, emitting nodes directly in the reference's
-// flattened pre-order (src/bvhaccel.cpp:215-234).  The partition of a range does not
-// depend on the order ranges are visited in, so this reproduces the recursive build.
+// Top-down build in two steps.  (1) The ranges are split by jobs on the host thread pool into a
+// linked tree: the partition of a range depends only on the range's own primitives, and every range
+// is handled by exactly one job with the same std:: algorithms, so the tree is the one the
+// reference's recursion builds whatever the schedule.  (2) A serial walk numbers the nodes in the
+// reference's flattened pre-order (src/bvhaccel.cpp:215-234).
+struct LinkNode {                     // trivially constructible: the pool is never value-initialised
+    Bounds box;
+    uint32_t begin, end;
+    uint32_t left;                    // interior: children at left, left + 1; leaf: 0
+    uint32_t axis;
+};
+
+class LinkBuilder {
+public:
+    LinkBuilder(std::vector<Prim>& prims, int leafThreshold)
+        : prims_(prims), leafThreshold_(leafThreshold), nodes_(new LinkNode[2 * prims.size() + 2]) { }
+
+    void run()
+    {
+        unsigned nThreads = buildThreads();
+        if (prims_.size() < kSpawnAbove) nThreads = 1;
+        pool_.run(nThreads, Job{ 0u, 0u, static_cast<uint32_t>(prims_.size()) }, [this](const Job& j) { build(j); });
+    }
+
+    const LinkNode* nodes() const { return nodes_.get(); }
+
+private:
+    struct Job { uint32_t node, begin, end; };
+    static constexpr uint32_t kSpawnAbove = 16384;
+
+    void build(const Job& first)
+    {
+        std::vector<Job> stack{ first };
+        while (!stack.empty()) {
+            const Job j = stack.back();
+            stack.pop_back();
+            LinkNode& n = nodes_[j.node];
+            n.box.reset();
+            for (uint32_t i = j.begin; i < j.end; ++i) n.box.grow(prims_[i].box);
+            n.begin = j.begin;
+            n.end = j.end;
+            n.left = 0;
+            n.axis = 3;
+            if (static_cast<int>(j.end - j.begin) < leafThreshold_) continue;
+            n.axis = static_cast<uint32_t>(n.box.widestAxis());
+            const uint32_t mid = splitRange(prims_, j.begin, j.end, n.box, static_cast<int>(n.axis));
+            const uint32_t l = next_.fetch_add(2);
+            n.left = l;
+            const Job lj{ l, j.begin, mid }, rj{ l + 1, mid, j.end };
+            if (j.end - j.begin > kSpawnAbove) { pool_.spawn(lj); pool_.spawn(rj); }
+            else { stack.push_back(rj); stack.push_back(lj); }
+        }
+    }
+
+    std::vector<Prim>& prims_;
+    int leafThreshold_;
+    std::unique_ptr<LinkNode[]> nodes_;
+    std::atomic<uint32_t> next_{ 1 };
+    TaskPool<Job> pool_;
+};
+
 void buildFlat(std::vector<Prim>& prims, int leafThreshold, FlatTree& t)
 {
-    std::vector<Task> stack;
-    stack.push_back(Task{ 0u, static_cast<uint32_t>(prims.size()), -1, 1 });
+    LinkBuilder lb(prims, leafThreshold);
+    lb.run();
+    const LinkNode* ln = lb.nodes();
+    struct Visit { uint32_t node; int32_t parent; int depth; };
+    std::vector<Visit> stack{ Visit{ 0u, -1, 1 } };
     while (!stack.empty()) {
-        const Task task = stack.back();
+        const Visit v = stack.back();
         stack.pop_back();
+        const LinkNode& n = ln[v.node];
         const uint32_t idx = static_cast<uint32_t>(t.box.size());
-        if (task.parent >= 0) t.right[task.parent] = idx;   // only right children carry a parent
-        Bounds b;
-        b.reset();
-        for (uint32_t i = task.begin; i < task.end; ++i) b.grow(prims[i].box);
-        t.box.push_back(b);
+        if (v.parent >= 0) t.right[v.parent] = idx;         // only right children carry a parent
+        t.box.push_back(n.box);
         t.right.push_back(0);
-        t.begin.push_back(task.begin);
-        t.end.push_back(task.end);
-        t.depth = std::max(t.depth, task.depth);
-        if (static_cast<int>(task.end - task.begin) < leafThreshold) {
-            t.axis.push_back(3);
-            continue;
-        }
-        const int axis = b.widestAxis();
-        t.axis.push_back(static_cast<uint8_t>(axis));
-        const uint32_t mid = splitRange(prims, task.begin, task.end, b, axis);
-        // left child is emitted next (index idx+1); the right one when the left subtree is done
-        stack.push_back(Task{ mid, task.end, static_cast<int32_t>(idx), task.depth + 1 });
-        stack.push_back(Task{ task.begin, mid, -1, task.depth + 1 });
+        t.begin.push_back(n.begin);
+        t.end.push_back(n.end);
+        t.axis.push_back(static_cast<uint8_t>(n.axis));
+        t.depth = std::max(t.depth, v.depth);
+        if (n.axis == 3) continue;
+        // left child is numbered next (idx + 1); the right one when the left subtree is done
+        stack.push_back(Visit{ n.left + 1, static_cast<int32_t>(idx), v.depth + 1 });
+        stack.push_back(Visit{ n.left, -1, v.depth + 1 });
     }
 }
 
@@ -175,11 +229,13 @@ void emitPairs(const FlatTree& t, const std::vector<uint32_t>& slotOfLeaf, std::
     empty.split_axis = 3;
     pairs[0].child[0] = record(0);
     pairs[0].child[1] = empty;
-    for (size_t i = 0; i < n; ++i) {
-        if (t.axis[i] == 3) continue;
-        pairs[pairOf[i]].child[0] = record(static_cast<uint32_t>(i) + 1);
-        pairs[pairOf[i]].child[1] = record(t.right[i]);
-    }
+    parallelChunks(n, buildThreads(), size_t(1) << 15, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            if (t.axis[i] == 3) continue;
+            pairs[pairOf[i]].child[0] = record(static_cast<uint32_t>(i) + 1);
+            pairs[pairOf[i]].child[1] = record(t.right[i]);
+        }
+    });
 }
 
 // include/triaccel.h:54-108
@@ -222,22 +278,27 @@ int buildTriangleBvh(const float* verts, size_t nVerts, const int32_t* tris, siz
         return YART_ERR_INVALID_ARGUMENT;
     }
     std::vector<Prim> prims(nTris);
-    for (size_t i = 0; i < nTris; ++i) {
-        const int32_t* t = tris + i * 5;
-        for (int c = 0; c < 3; ++c) {
-            if (t[c] < 0 || static_cast<size_t>(t[c]) >= nVerts) {
-                err = "yart_accel_create: vertex index out of range";
-                return YART_ERR_INVALID_ARGUMENT;
-            }
+    const unsigned nThreads = buildThreads();
+    std::atomic<bool> badIndex{ false };
+    parallelChunks(nTris, nThreads, size_t(1) << 16, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            const int32_t* t = tris + i * 5;
+            bool ok = true;
+            for (int c = 0; c < 3; ++c) ok = ok && t[c] >= 0 && static_cast<size_t>(t[c]) < nVerts;
+            if (!ok) { badIndex = true; return; }
+            Prim& p = prims[i];
+            const float* v0 = verts + static_cast<size_t>(t[0]) * 3;
+            std::memcpy(p.box.lo, v0, 12);                              // BBox(point), include/bbox.h:22
+            std::memcpy(p.box.hi, v0, 12);
+            p.box.growPoint(verts + static_cast<size_t>(t[1]) * 3);     // src/bvhaccel.cpp:337-339
+            p.box.growPoint(verts + static_cast<size_t>(t[2]) * 3);
+            for (int a = 0; a < 3; ++a) p.centre[a] = (p.box.lo[a] + p.box.hi[a]) * 0.5f;   // :28
+            p.id = static_cast<uint32_t>(i);
         }
-        Prim& p = prims[i];
-        const float* v0 = verts + static_cast<size_t>(t[0]) * 3;
-        std::memcpy(p.box.lo, v0, 12);                              // BBox(point), include/bbox.h:22
-        std::memcpy(p.box.hi, v0, 12);
-        p.box.growPoint(verts + static_cast<size_t>(t[1]) * 3);     // src/bvhaccel.cpp:337-339
-        p.box.growPoint(verts + static_cast<size_t>(t[2]) * 3);
-        for (int a = 0; a < 3; ++a) p.centre[a] = (p.box.lo[a] + p.box.hi[a]) * 0.5f;   // :28
-        p.id = static_cast<uint32_t>(i);
+    });
+    if (badIndex) {
+        err = "yart_accel_create: vertex index out of range";
+        return YART_ERR_INVALID_ARGUMENT;
     }
 
     const bool timing = std::getenv("YART_BUILD_TIMING") != nullptr;
@@ -259,26 +320,28 @@ int buildTriangleBvh(const float* verts, size_t nVerts, const int32_t* tris, siz
     out.nodes.assign(nNodes, YartBvhNode{});
     out.triaccel.assign(nTris, YartTriAccel{});
     out.slotOfInput.assign(nTris, 0);
-    for (size_t i = 0; i < nNodes; ++i) {
-        YartBvhNode& n = out.nodes[i];
-        std::memcpy(n.bounds_min, t.box[i].lo, 12);
-        std::memcpy(n.bounds_max, t.box[i].hi, 12);
-        n.split_axis = t.axis[i];
-        if (t.axis[i] == 3) {
-            n.offset = slot[i];
-            n.num_triangles = static_cast<uint8_t>(t.end[i] - t.begin[i]);
-            for (uint32_t j = t.begin[i]; j < t.end[i]; ++j) {      // src/bvhaccel.cpp:354-360
-                const int32_t* tr = tris + static_cast<size_t>(prims[j].id) * 5;
-                out.slotOfInput[prims[j].id] = slot[i] + (j - t.begin[i]);
-                projectTriangle(out.triaccel[slot[i] + (j - t.begin[i])],
-                                verts + static_cast<size_t>(tr[0]) * 3,
-                                verts + static_cast<size_t>(tr[1]) * 3,
-                                verts + static_cast<size_t>(tr[2]) * 3, tr[4], tr[3]);
+    parallelChunks(nNodes, nThreads, size_t(1) << 14, [&](size_t nb, size_t ne) {
+        for (size_t i = nb; i < ne; ++i) {
+            YartBvhNode& n = out.nodes[i];
+            std::memcpy(n.bounds_min, t.box[i].lo, 12);
+            std::memcpy(n.bounds_max, t.box[i].hi, 12);
+            n.split_axis = t.axis[i];
+            if (t.axis[i] == 3) {
+                n.offset = slot[i];
+                n.num_triangles = static_cast<uint8_t>(t.end[i] - t.begin[i]);
+                for (uint32_t j = t.begin[i]; j < t.end[i]; ++j) {      // src/bvhaccel.cpp:354-360
+                    const int32_t* tr = tris + static_cast<size_t>(prims[j].id) * 5;
+                    out.slotOfInput[prims[j].id] = slot[i] + (j - t.begin[i]);
+                    projectTriangle(out.triaccel[slot[i] + (j - t.begin[i])],
+                                    verts + static_cast<size_t>(tr[0]) * 3,
+                                    verts + static_cast<size_t>(tr[1]) * 3,
+                                    verts + static_cast<size_t>(tr[2]) * 3, tr[4], tr[3]);
+                }
+            } else {
+                n.offset = t.right[i];
             }
-        } else {
-            n.offset = t.right[i];
         }
-    }
+    });
     if (nNodes - 1 >= kMaxPairs) {
         err = "too many BVH nodes";
         return YART_ERR_INVALID_ARGUMENT;
