@@ -203,6 +203,53 @@ int yart_build_wide_host(const float* verts, size_t n_verts, const int32_t* tris
                          void* nodes_out, size_t* n_nodes, void* rows_a_out, void* rows_bc_out,
                          size_t* n_prims, int* depth);
 
+/* ---- Scene ingestion -------------------------------------------------------------
+ * Replaces Scene::loadFromObj(folder, file) (src/scene.cpp:159-298) and, beneath it, the bundled
+ * tinyobjloader's LoadObj / LoadMtl (external/tinyobjloader/tiny_obj_loader.h:838-1133, :587-813):
+ * Wavefront OBJ + MTL -> the flat scene yart_accel_create takes.  Same meshes (one per usemtl / g / o
+ * run of faces), same per-mesh vertex numbering, same triangles, same float bits (tinyobjloader's own
+ * number conversion, not strtod), per-vertex normals from the file or generated as
+ * include/triangle.h:76-111 does, the mesh's material, and the light sphere the reference appends to
+ * every OBJ scene.  Host-only: no HIP call.  The reference ignores load failures; this returns
+ * YART_ERR_INVALID_ARGUMENT when the file cannot be opened or a face names a vertex that does
+ * not exist. */
+typedef struct YartObjScene YartObjScene;
+
+typedef struct YartObjMesh {        /* 24 bytes */
+    int32_t first_vertex;           /* into the concatenated vertex / normal arrays */
+    int32_t num_vertices;
+    int32_t first_triangle;
+    int32_t num_triangles;
+    int32_t material;               /* index into the materials, -1: none named (the reference
+                                       indexes its Bsdf list with -1 there, src/scene.cpp:261-266) */
+    int32_t normals_from_file;      /* 1: `vn` of the file, 0: generated */
+} YartObjMesh;
+
+typedef struct YartObjMaterial {    /* 40 bytes: what src/scene.cpp:172-208 reads of a material */
+    float diffuse[3];
+    float specular[3];
+    float shininess;
+    float ior;
+    int32_t illum;
+    int32_t bsdf;                   /* 0 Lambertian(diffuse), 1 Torrance-Sparrow conductor(shininess),
+                                       2 Fresnel dielectric(ior), 3 black Lambertian (src/scene.cpp:183-207) */
+} YartObjMaterial;
+
+int yart_obj_load(const char* folder, const char* file, YartObjScene** out);
+void yart_obj_free(YartObjScene* scene);
+size_t yart_obj_num_meshes(const YartObjScene* scene);
+size_t yart_obj_num_vertices(const YartObjScene* scene);
+size_t yart_obj_num_triangles(const YartObjScene* scene);
+size_t yart_obj_num_materials(const YartObjScene* scene);
+size_t yart_obj_num_spheres(const YartObjScene* scene);
+/* Copies out whichever arrays are non-NULL: verts / normals 3 floats per vertex (meshes
+ * concatenated), tris 5 int32 per triangle as yart_accel_create takes them (vertex numbers already
+ * offset by the mesh's first_vertex), spheres 4 floats each. */
+int yart_obj_get(const YartObjScene* scene, float* verts, float* normals, int32_t* tris, float* spheres,
+                 YartObjMesh* meshes, YartObjMaterial* materials);
+const char* yart_obj_mesh_name(const YartObjScene* scene, size_t mesh);
+const char* yart_obj_material_name(const YartObjScene* scene, size_t material);
+
 /* Per-kernel timing (no counterpart in the reference, which only has a wall-clock
  * Timer around the whole render, include/timer.h:6-26).  While enabled, every
  * intersect call brackets its launches with HIP events on the caller's stream, in three

@@ -241,6 +241,27 @@ def reference_uniform_sphere(u12, so=None):
     return out
 
 
+def reference_load_obj(folder, file, so=None):
+    """The reference's Scene::loadFromObj (src/scene.cpp:159-298) flattened; the material table comes
+    from its bundled tinyobjloader called directly.  The reference prints the scene to stdout."""
+    L = ctypes.CDLL(so or REF_SO)
+    L.ref_obj_load.restype = c_vp
+    L.ref_obj_load.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    L.ref_obj_counts.argtypes = [c_vp] + [ctypes.POINTER(c_sz)] * 5
+    L.ref_obj_get.argtypes = [c_vp] * 7
+    L.ref_obj_free.argtypes = [c_vp]
+    h = L.ref_obj_load(os.fsencode(folder), os.fsencode(file))
+    n = [c_sz() for _ in range(5)]
+    L.ref_obj_counts(h, *[ctypes.byref(x) for x in n])
+    nm, nv, nt, ns, nmat = [x.value for x in n]
+    out = {"verts": np.zeros((nv, 3), np.float32), "normals": np.zeros((nv, 3), np.float32),
+           "tris": np.zeros((nt, 5), np.int32), "spheres": np.zeros((ns, 4), np.float32),
+           "meshes": np.zeros((nm, 6), np.int32), "materials": np.zeros((nmat, 9), np.float32)}
+    L.ref_obj_get(h, *[out[k].ctypes.data_as(c_vp) for k in ("verts", "normals", "tris", "spheres", "meshes", "materials")])
+    L.ref_obj_free(h)
+    return out
+
+
 _ENGINE_CLOSEST = ctypes.CFUNCTYPE(ctypes.c_int, c_vp, c_vp, c_sz, c_vp, ctypes.c_uint)
 _ENGINE_ANY = ctypes.CFUNCTYPE(ctypes.c_int, c_vp, c_vp, c_sz, c_vp, ctypes.c_uint)
 

@@ -38,6 +38,7 @@
 #define private public
 #include "scene.h"
 #include "camera.h"
+#include "tiny_obj_loader.h"
 // FlattenedBvhNode is only defined inside the .cpp (src/bvhaccel.cpp:64), so
 // this TU *is* the bvhaccel translation unit of the reference build.
 #include "../src/bvhaccel.cpp"
@@ -726,5 +727,68 @@ void ref_uniform_sphere(const float* u12, size_t n, float* dirOut)
         dirOut[i * 3 + 0] = d.x; dirOut[i * 3 + 1] = d.y; dirOut[i * 3 + 2] = d.z;
     }
 }
+
+// ---- Scene ingestion: the reference's own Scene::loadFromObj (src/scene.cpp:159-298)
+// and, for the material table it does not keep, its bundled tinyobjloader called directly.
+struct RefObj {
+    std::vector<float> verts, normals, spheres, materials;     // materials: 9 floats each
+    std::vector<int32_t> tris, meshes;                          // meshes: 6 ints each (= YartObjMesh)
+};
+
+void* ref_obj_load(const char* folder, const char* file)
+{
+    auto* o = new RefObj();
+    Scene s = Scene::loadFromObj(folder, file);
+    std::vector<tinyobj::shape_t> shapes;
+    std::vector<tinyobj::material_t> materials;
+    std::string err;
+    tinyobj::LoadObj(shapes, materials, err, (std::string(folder) + file).c_str(), folder);
+    int32_t v0 = 0, t0 = 0;
+    for (size_t m = 0; m < s.meshes_.size(); ++m) {
+        const auto& mesh = s.meshes_[m];
+        for (const auto& v : mesh.vertices_) { o->verts.push_back(v.x); o->verts.push_back(v.y); o->verts.push_back(v.z); }
+        for (const auto& n : mesh.normals_) { o->normals.push_back(n.x); o->normals.push_back(n.y); o->normals.push_back(n.z); }
+        int32_t k = 0;
+        for (const auto& t : mesh.triangles_) {
+            const int32_t rec[5] = { t.idx0 + v0, t.idx1 + v0, t.idx2 + v0, (int32_t)m, k++ };
+            o->tris.insert(o->tris.end(), rec, rec + 5);
+        }
+        const auto& tm = shapes[m].mesh;
+        const int32_t rec[6] = { v0, (int32_t)mesh.vertices_.size(), t0, (int32_t)mesh.triangles_.size(),
+                                 tm.material_ids[0], tm.positions.size() == tm.normals.size() ? 1 : 0 };
+        o->meshes.insert(o->meshes.end(), rec, rec + 6);
+        v0 += (int32_t)mesh.vertices_.size();
+        t0 += (int32_t)mesh.triangles_.size();
+    }
+    for (const auto& sh : s.shapes_) {
+        auto* sp = static_cast<Sphere*>(sh.get());
+        o->spheres.insert(o->spheres.end(), { sp->position_.x, sp->position_.y, sp->position_.z, sp->radius_ });
+    }
+    for (const auto& m : materials) {
+        o->materials.insert(o->materials.end(), { m.diffuse[0], m.diffuse[1], m.diffuse[2], m.specular[0], m.specular[1],
+                                                  m.specular[2], m.shininess, m.ior, (float)m.illum });
+    }
+    return o;
+}
+
+void ref_obj_counts(void* h, size_t* nMeshes, size_t* nVerts, size_t* nTris, size_t* nSpheres, size_t* nMaterials)
+{
+    auto* o = static_cast<RefObj*>(h);
+    *nMeshes = o->meshes.size() / 6; *nVerts = o->verts.size() / 3; *nTris = o->tris.size() / 5;
+    *nSpheres = o->spheres.size() / 4; *nMaterials = o->materials.size() / 9;
+}
+
+void ref_obj_get(void* h, float* verts, float* normals, int32_t* tris, float* spheres, int32_t* meshes, float* materials)
+{
+    auto* o = static_cast<RefObj*>(h);
+    std::memcpy(verts, o->verts.data(), o->verts.size() * 4);
+    std::memcpy(normals, o->normals.data(), o->normals.size() * 4);
+    std::memcpy(tris, o->tris.data(), o->tris.size() * 4);
+    std::memcpy(spheres, o->spheres.data(), o->spheres.size() * 4);
+    std::memcpy(meshes, o->meshes.data(), o->meshes.size() * 4);
+    std::memcpy(materials, o->materials.data(), o->materials.size() * 4);
+}
+
+void ref_obj_free(void* h) { delete static_cast<RefObj*>(h); }
 
 } // extern "C"

@@ -1,0 +1,190 @@
+"""Scene ingestion: yart_obj_load must hand over the scene the reference's
+Scene::loadFromObj (src/scene.cpp:159-298, bundled tinyobjloader) builds from the same files --
+same meshes, vertex numbering, triangles, float bits, vertex normals, materials, light sphere.
+CPU: against the golden outputs of the real reference (tests/golden/g5_obj_*.npz, made by
+oracle/make_golden_obj.py) and, where the real reference is built, against it live on a fuzzed file.
+GPU: a loaded scene goes through yart_accel_create and is traced with parity against the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, bits
+from yart_amd import api
+
+OBJ_DIR = os.path.join(ROOT, "tests", "golden", "obj") + os.sep
+FIXTURES = ["syntax", "terrain"]
+
+
+def same_bits(a, b):
+    """Bit equality; two NaNs count as equal (their payload depends on operand order)."""
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.dtype.kind == "f":
+        ok = (bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))
+    else:
+        ok = a == b
+    assert ok.all(), "%d of %d differ, first at %s" % ((~ok).sum(), ok.size, np.argwhere(~ok)[:3].tolist())
+
+
+def mesh_table(o):
+    return np.stack([o["meshes"][k] for k in o["meshes"].dtype.names], -1)
+
+
+def material_table(o):
+    m = o["materials"]
+    return np.concatenate([m["diffuse"], m["specular"], m["shininess"][:, None], m["ior"][:, None],
+                           m["illum"][:, None].astype(np.float32)], 1).reshape(-1, 9)
+
+
+def assert_same_scene(o, g):
+    same_bits(o["verts"], g["verts"])
+    same_bits(o["tris"], g["tris"])
+    same_bits(o["normals"], g["normals"])
+    same_bits(o["spheres"], g["spheres"])
+    same_bits(mesh_table(o), g["meshes"])
+    same_bits(material_table(o), g["materials"])
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_ingestion_matches_reference_golden(name):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g5_obj_%s.npz" % name))
+    o = api.load_obj(OBJ_DIR, name + ".obj")
+    assert_same_scene(o, g)
+    assert np.array_equal(o["spheres"], np.array([[0.0, 1.0, -0.5, 0.05]], np.float32))     # src/scene.cpp:280-283
+
+
+def test_syntax_fixture_details():
+    o = api.load_obj(OBJ_DIR, "syntax.obj")
+    # a missing mtllib still contributes one unnamed default material (tiny_obj_loader.h:809-812, :827-835)
+    assert o["material_names"] == ["", "white", "metal", "glass", "white", "odd"]
+    assert o["materials"]["bsdf"].tolist() == [3, 0, 1, 2, 0, 3]                # src/scene.cpp:183-207
+    assert o["materials"]["shininess"][5] == 0.0 and o["materials"]["ior"][5] == 0.0       # "1e", ".5" do not parse
+    assert o["meshes"]["normals_from_file"].tolist() == [1, 0, 0, 0, 0, 0]
+    assert o["meshes"]["material"].tolist() == [1, 2, 3, 5, 1, 2]               # the second "white" never wins
+
+
+def fuzz_obj(path, seed):
+    """Numbers in every spelling the grammar allows, polygons of 3..7 corners, all four corner forms."""
+    rng = np.random.default_rng(seed)
+    lines = ["mtllib fuzz.mtl", "usemtl a"]
+    nv, nn = 600, 50
+
+    def num():
+        x = float(rng.normal()) * 10.0 ** int(rng.integers(-6, 7))
+        kind = int(rng.integers(0, 6))
+        digits = int(rng.integers(0, 18))
+        if kind == 0:
+            return "%.*f" % (digits, x)
+        if kind == 1:
+            return "%.*e" % (digits, x)
+        if kind == 2:
+            return "%.*g" % (max(1, digits), x)
+        if kind == 3:
+            return "%+.*E" % (digits, x)
+        if kind == 4:
+            return "%d" % int(x)
+        return repr(x)
+
+    for _ in range(nv):
+        lines.append("v %s %s\t%s" % (num(), num(), num()))
+    for _ in range(nn):
+        lines.append("vn %s %s %s" % (num(), num(), num()))
+    lines.append("vt 0.5 0.5")
+    for g in range(6):
+        lines.append(["g part%d" % g, "o obj%d" % g, "usemtl b", "usemtl a"][g % 4])
+        form = g % 4
+        for _ in range(int(rng.integers(20, 120))):
+            corners = []
+            for _ in range(int(rng.integers(3, 8))):
+                v = int(rng.integers(1, nv + 1))
+                if rng.random() < 0.3:
+                    v -= nv + 1
+                n = int(rng.integers(1, nn + 1))
+                corners.append([str(v), "%d/1" % v, "%d//%d" % (v, n), "%d/1/%d" % (v, n)][form])
+            lines.append("f " + " ".join(corners))
+    with open(os.path.join(path, "fuzz.obj"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    with open(os.path.join(path, "fuzz.mtl"), "w") as f:
+        f.write("newmtl a\nKd %s %s %s\nillum 2\nnewmtl b\nNs %s\nNi %s\nillum 7\n" % (num(), num(), num(), num(), num()))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_ingestion_matches_live_reference_on_fuzzed_file(tmp_path, seed):
+    from oracle import oracle as orc
+    if not os.path.exists(orc.REF_SO):
+        pytest.skip("the real reference is only built in the authoring container")
+    fuzz_obj(str(tmp_path), seed)
+    folder = str(tmp_path) + os.sep
+    g = orc.reference_load_obj(folder, "fuzz.obj")
+    o = api.load_obj(folder, "fuzz.obj")
+    assert len(o["tris"]) > 300
+    assert_same_scene(o, g)
+
+
+def test_missing_file_and_bad_index_are_errors(tmp_path):
+    with pytest.raises(api.YartError, match="cannot open"):
+        api.load_obj(str(tmp_path) + os.sep, "nothing.obj")
+    (tmp_path / "bad.obj").write_text("v 0 0 0\nv 1 0 0\nf 1 2 5\n")
+    with pytest.raises(api.YartError, match="does not exist"):
+        api.load_obj(str(tmp_path) + os.sep, "bad.obj")
+
+
+def test_cxx_shim_load_from_obj(tmp_path):
+    """yart_amd::Scene::loadFromObj (yart_shim.hpp) holds the same meshes."""
+    exe = os.path.join(ROOT, "tests", "cxx", "_build", "test_obj")
+    src = os.path.join(ROOT, "tests", "cxx", "test_obj.cpp")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    lib_dir = os.path.join(ROOT, "yart_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", src, "-o", exe, "-L" + lib_dir, "-lyart_amd",
+                           "-Wl,-rpath," + lib_dir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    out = tmp_path / "out.bin"
+    r = subprocess.run([exe, OBJ_DIR, "terrain.obj", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g5_obj_terrain.npz"))
+    raw = out.read_bytes()
+    counts = np.frombuffer(raw[:40], np.uint64)
+    assert counts.tolist() == [len(g["meshes"]), len(g["verts"]), len(g["tris"]), 1, len(g["materials"])]
+    pos = 40
+    for first_v, nv, first_t, nt, material, _ in g["meshes"]:
+        c = np.frombuffer(raw[pos:pos + 16], np.uint64)
+        assert c.tolist() == [nv, nt]
+        pos += 16
+        v = np.frombuffer(raw[pos:pos + nv * 12], np.float32).reshape(-1, 3); pos += nv * 12
+        n = np.frombuffer(raw[pos:pos + nv * 12], np.float32).reshape(-1, 3); pos += nv * 12
+        t = np.frombuffer(raw[pos:pos + nt * 12], np.int32).reshape(-1, 3); pos += nt * 12
+        m = np.frombuffer(raw[pos:pos + 4], np.int32)[0]; pos += 4
+        same_bits(v, g["verts"][first_v:first_v + nv])
+        same_bits(n, g["normals"][first_v:first_v + nv])
+        same_bits(t, g["tris"][first_t:first_t + nt, :3] - first_v)
+        assert m == material
+    r = subprocess.run([exe, OBJ_DIR, "absent.obj", str(out)], capture_output=True, text=True)
+    assert r.returncode == 4 and "cannot open" in r.stderr
+
+
+@pytest.mark.gpu
+def test_loaded_scene_traces_like_the_oracle():
+    """OBJ -> yart_accel_create -> closest / any hit, against the oracle on the same flat scene."""
+    import torch
+    from oracle import oracle as orc
+    o = api.load_obj(OBJ_DIR, "terrain.obj")
+    rng = np.random.default_rng(3)
+    n = 20000
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0:3] = rng.uniform(-2.5, 2.5, (n, 3)) * [1, 0.2, 1] + [0, 1.2, 0]
+    d = rng.normal(size=(n, 3)) * [1, 1, 1] - [0, 0.8, 0]
+    rays[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays[:, 7] = np.inf
+    ref = orc.Oracle(o["verts"], o["tris"], o["spheres"])
+    want = ref.intersect(rays)
+    acc = api.Accel(o["verts"], o["tris"], o["spheres"])
+    for flags in (api.YART_DEFAULT, api.YART_REFERENCE_RULE):
+        got = api.hits_to_numpy(acc.intersect_closest(torch.from_numpy(rays).cuda(), flags=flags))
+        assert (got["prim"] >= 0).sum() > n // 10
+        assert np.array_equal(got["prim"], want["prim"])
+        assert np.array_equal(bits(got["t"]), bits(want["t"]))
+    sh = rays.copy()
+    sh[:, 7] = rng.uniform(0.0, 3.0, n).astype(np.float32)
+    occ = acc.intersect_any(torch.from_numpy(sh).cuda()).cpu().numpy()
+    assert np.array_equal(occ.astype(bool), ref.intersect_shadow(sh).astype(bool))

@@ -37,7 +37,14 @@ EXPORTS = [
     "yart_accel_device_bytes", "yart_build_host", "yart_status_string", "yart_last_error",
     "yart_accel_profile_enable", "yart_accel_profile_read",
     "yart_build_wide_host", "yart_accel_num_wide_nodes", "yart_accel_num_wide_prims", "yart_accel_wide_depth", "yart_accel_get_wide",
+    "yart_obj_load", "yart_obj_free", "yart_obj_num_meshes", "yart_obj_num_vertices", "yart_obj_num_triangles",
+    "yart_obj_num_materials", "yart_obj_num_spheres", "yart_obj_get", "yart_obj_mesh_name", "yart_obj_material_name",
 ]
+
+OBJ_MESH_DTYPE = np.dtype([("first_vertex", np.int32), ("num_vertices", np.int32), ("first_triangle", np.int32),
+                           ("num_triangles", np.int32), ("material", np.int32), ("normals_from_file", np.int32)])
+OBJ_MATERIAL_DTYPE = np.dtype([("diffuse", np.float32, 3), ("specular", np.float32, 3), ("shininess", np.float32),
+                               ("ior", np.float32), ("illum", np.int32), ("bsdf", np.int32)])
 
 _vp = ctypes.c_void_p
 _sz = ctypes.c_size_t
@@ -81,6 +88,17 @@ def lib():
     L.yart_accel_profile_enable.argtypes = [_vp, ctypes.c_int]
     L.yart_accel_profile_read.argtypes = [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                           ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
+    L.yart_obj_load.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(_vp)]
+    L.yart_obj_free.argtypes = [_vp]
+    L.yart_obj_free.restype = None
+    for name in ("yart_obj_num_meshes", "yart_obj_num_vertices", "yart_obj_num_triangles", "yart_obj_num_materials",
+                 "yart_obj_num_spheres"):
+        getattr(L, name).argtypes = [_vp]
+        getattr(L, name).restype = _sz
+    L.yart_obj_get.argtypes = [_vp] * 7
+    for name in ("yart_obj_mesh_name", "yart_obj_material_name"):
+        getattr(L, name).argtypes = [_vp, _sz]
+        getattr(L, name).restype = ctypes.c_char_p
     L.yart_status_string.argtypes = [ctypes.c_int]
     L.yart_status_string.restype = ctypes.c_char_p
     L.yart_last_error.restype = ctypes.c_char_p
@@ -131,6 +149,30 @@ def build_wide_host(verts, tris, spheres=None, max_leaf=1):
     rows_bc = np.zeros((npr.value, 8), np.float32)
     _check(L.yart_build_wide_host(*args, _p(nodes), ctypes.byref(nn), _p(rows_a), _p(rows_bc), ctypes.byref(npr), ctypes.byref(depth)))
     return nodes, rows_a, rows_bc, depth.value
+
+
+def load_obj(folder, file):
+    """OBJ + MTL -> flat scene (yart_obj_load; host-only).  Returns a dict: verts [v,3], normals [v,3],
+    tris [t,5], spheres [s,4], meshes (OBJ_MESH_DTYPE), materials (OBJ_MATERIAL_DTYPE), mesh_names,
+    material_names.  verts / tris / spheres go to Accel() unchanged."""
+    L = lib()
+    h = _vp()
+    _check(L.yart_obj_load(os.fsencode(folder), os.fsencode(file), ctypes.byref(h)))
+    try:
+        out = {
+            "verts": np.zeros((L.yart_obj_num_vertices(h), 3), np.float32),
+            "normals": np.zeros((L.yart_obj_num_vertices(h), 3), np.float32),
+            "tris": np.zeros((L.yart_obj_num_triangles(h), 5), np.int32),
+            "spheres": np.zeros((L.yart_obj_num_spheres(h), 4), np.float32),
+            "meshes": np.zeros(L.yart_obj_num_meshes(h), OBJ_MESH_DTYPE),
+            "materials": np.zeros(L.yart_obj_num_materials(h), OBJ_MATERIAL_DTYPE),
+        }
+        _check(L.yart_obj_get(h, *[_p(out[k]) for k in ("verts", "normals", "tris", "spheres", "meshes", "materials")]))
+        out["mesh_names"] = [L.yart_obj_mesh_name(h, i).decode() for i in range(len(out["meshes"]))]
+        out["material_names"] = [L.yart_obj_material_name(h, i).decode() for i in range(len(out["materials"]))]
+        return out
+    finally:
+        L.yart_obj_free(h)
 
 
 class Accel:

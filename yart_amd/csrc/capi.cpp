@@ -10,6 +10,7 @@
 #include <limits>
 #include <mutex>
 #include <new>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -17,6 +18,7 @@
 #include "bvh_build.h"
 #include "traverse.h"
 #include "wide_build.h"
+#include "obj_ingest.h"
 
 namespace {
 
@@ -578,6 +580,84 @@ int yart_accel_profile_read(YartAccel* a, double* ms_sort, double* ms_spheres, d
     if (n_calls) *n_calls = a->profiledCalls;
     a->profiledCalls = 0;
     return st;
+}
+
+struct YartObjScene {
+    yart::ObjScene scene;
+    size_t numVertices = 0, numTriangles = 0;
+};
+
+int yart_obj_load(const char* folder, const char* file, YartObjScene** out)
+{
+    if (!file || !out) return fail(YART_ERR_INVALID_ARGUMENT, "yart_obj_load: null argument");
+    *out = nullptr;
+    auto s = std::make_unique<YartObjScene>();
+    std::string err;
+    if (!yart::loadObjScene(folder ? folder : "", file, s->scene, err)) return fail(YART_ERR_INVALID_ARGUMENT, "yart_obj_load: " + err);
+    for (const auto& m : s->scene.meshes) {
+        s->numVertices += m.positions.size() / 3;
+        s->numTriangles += m.indices.size() / 3;
+    }
+    if (s->numVertices > 0x7fffffffu || s->numTriangles > 0x7fffffffu) return fail(YART_ERR_INVALID_ARGUMENT, "yart_obj_load: scene too large");
+    *out = s.release();
+    return YART_OK;
+}
+
+void yart_obj_free(YartObjScene* scene) { delete scene; }
+size_t yart_obj_num_meshes(const YartObjScene* s) { return s ? s->scene.meshes.size() : 0; }
+size_t yart_obj_num_vertices(const YartObjScene* s) { return s ? s->numVertices : 0; }
+size_t yart_obj_num_triangles(const YartObjScene* s) { return s ? s->numTriangles : 0; }
+size_t yart_obj_num_materials(const YartObjScene* s) { return s ? s->scene.materials.size() : 0; }
+size_t yart_obj_num_spheres(const YartObjScene* s) { return s ? s->scene.spheres.size() / 4 : 0; }
+
+int yart_obj_get(const YartObjScene* s, float* verts, float* normals, int32_t* tris, float* spheres,
+                 YartObjMesh* meshes, YartObjMaterial* materials)
+{
+    if (!s) return fail(YART_ERR_INVALID_ARGUMENT, "yart_obj_get: null scene");
+    size_t v0 = 0, t0 = 0;
+    for (size_t mi = 0; mi < s->scene.meshes.size(); ++mi) {
+        const yart::ObjMesh& m = s->scene.meshes[mi];
+        const size_t nv = m.positions.size() / 3, nt = m.indices.size() / 3;
+        if (verts) std::memcpy(verts + v0 * 3, m.positions.data(), nv * 12);
+        if (normals) std::memcpy(normals + v0 * 3, m.normals.data(), nv * 12);
+        if (tris) {
+            for (size_t t = 0; t < nt; ++t) {
+                int32_t* r = tris + (t0 + t) * 5;
+                for (int k = 0; k < 3; ++k) r[k] = m.indices[t * 3 + k] + static_cast<int32_t>(v0);
+                r[3] = static_cast<int32_t>(mi);
+                r[4] = static_cast<int32_t>(t);
+            }
+        }
+        if (meshes) {
+            meshes[mi] = YartObjMesh{ static_cast<int32_t>(v0), static_cast<int32_t>(nv), static_cast<int32_t>(t0),
+                                      static_cast<int32_t>(nt), m.material, m.normalsFromFile ? 1 : 0 };
+        }
+        v0 += nv;
+        t0 += nt;
+    }
+    if (spheres && !s->scene.spheres.empty()) std::memcpy(spheres, s->scene.spheres.data(), s->scene.spheres.size() * 4);
+    if (materials) {
+        for (size_t i = 0; i < s->scene.materials.size(); ++i) {
+            const yart::ObjMaterial& m = s->scene.materials[i];
+            YartObjMaterial& o = materials[i];
+            std::memcpy(o.diffuse, m.diffuse, 12);
+            std::memcpy(o.specular, m.specular, 12);
+            o.shininess = m.shininess;
+            o.ior = m.ior;
+            o.illum = m.illum;
+            o.bsdf = yart::objBsdfKind(m);
+        }
+    }
+    return YART_OK;
+}
+
+const char* yart_obj_mesh_name(const YartObjScene* s, size_t i)
+{
+    return s && i < s->scene.meshes.size() ? s->scene.meshes[i].name.c_str() : "";
+}
+const char* yart_obj_material_name(const YartObjScene* s, size_t i)
+{
+    return s && i < s->scene.materials.size() ? s->scene.materials[i].name.c_str() : "";
 }
 
 const char* yart_status_string(int status)

@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstdint>
 #include <limits>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -72,6 +73,7 @@ struct TriangleMesh {                   // the data of include/triangle.h:71-200
     std::vector<Vector3f> normals;      // per vertex (the reference generates them at :76-111 when absent)
     std::vector<Triangle> triangles;
     Bsdf* bsdf = nullptr;
+    int32_t material = -1;              // loadFromObj: index into Scene::getMaterials()
 
     Vector3f getNormal(int32_t tri) const               // include/triangle.h:158-164
     {
@@ -119,6 +121,46 @@ public:
     ~Scene() { delete accel_; }
     Scene(const Scene&) = delete;
     Scene& operator=(const Scene&) = delete;
+
+    // src/scene.cpp:159-298: OBJ + MTL -> meshes (vertices, normals from the file or generated,
+    // triangles, material number) + the light sphere the reference appends.  The caller makes its
+    // Bsdf objects from getMaterials() (YartObjMaterial::bsdf names the class src/scene.cpp:183-207
+    // picks) and hangs them on the meshes; a Scene is not copyable here, hence the pointer.
+    static std::unique_ptr<Scene> loadFromObj(const std::string& folder, const std::string& file)
+    {
+        YartObjScene* h = nullptr;
+        check(yart_obj_load(folder.c_str(), file.c_str(), &h));
+        std::vector<float> v(yart_obj_num_vertices(h) * 3), n(v.size()), sph(yart_obj_num_spheres(h) * 4);
+        std::vector<int32_t> t(yart_obj_num_triangles(h) * 5);
+        std::vector<YartObjMesh> ms(yart_obj_num_meshes(h));
+        std::vector<YartObjMaterial> mats(yart_obj_num_materials(h));
+        const int st = yart_obj_get(h, v.data(), n.data(), t.data(), sph.data(), ms.data(), mats.data());
+        yart_obj_free(h);
+        check(st);
+        std::vector<TriangleMesh> meshes(ms.size());
+        for (size_t m = 0; m < ms.size(); ++m) {
+            TriangleMesh& mesh = meshes[m];
+            for (int32_t i = ms[m].first_vertex; i < ms[m].first_vertex + ms[m].num_vertices; ++i) {
+                mesh.vertices.emplace_back(v[i * 3], v[i * 3 + 1], v[i * 3 + 2]);
+                mesh.normals.emplace_back(n[i * 3], n[i * 3 + 1], n[i * 3 + 2]);
+            }
+            for (int32_t i = ms[m].first_triangle; i < ms[m].first_triangle + ms[m].num_triangles; ++i)
+                mesh.triangles.push_back(Triangle{ t[i * 5] - ms[m].first_vertex, t[i * 5 + 1] - ms[m].first_vertex,
+                                                   t[i * 5 + 2] - ms[m].first_vertex });
+            mesh.material = ms[m].material;
+        }
+        std::vector<Sphere> shapes;
+        for (size_t i = 0; i + 3 < sph.size(); i += 4) {
+            Sphere sp;
+            sp.radius = sph[i + 3];
+            sp.position = Vector3f(sph[i], sph[i + 1], sph[i + 2]);
+            shapes.push_back(sp);
+        }
+        std::unique_ptr<Scene> scene(new Scene(std::move(meshes), std::move(shapes)));
+        scene->materials_ = std::move(mats);
+        return scene;
+    }
+    const std::vector<YartObjMaterial>& getMaterials() const { return materials_; }
 
     // include/scene.h:37-74: build the acceleration structure (here: build + upload to `device`)
     void preprocess(int device = 0)
@@ -204,6 +246,7 @@ private:
 
     std::vector<TriangleMesh> meshes_;
     std::vector<Sphere> shapes_;
+    std::vector<YartObjMaterial> materials_;
     BvhAccel* accel_ = nullptr;
     unsigned flags_ = YART_DEFAULT;
 };
