@@ -250,6 +250,16 @@ int yart_obj_get(const YartObjScene* scene, float* verts, float* normals, int32_
 const char* yart_obj_mesh_name(const YartObjScene* scene, size_t mesh);
 const char* yart_obj_material_name(const YartObjScene* scene, size_t material);
 
+/* ---- Film output -------------------------------------------------------------------
+ * Replaces Camera::saveImage -> Bitmap::write (include/camera.h:53-56, src/bitmap.cpp:8-72): the
+ * float framebuffer (r,g,b per pixel, row 0 on top, as Camera::accumulate fills it) is tone-mapped
+ * with the reference's curve, min(255, (uint8)(powf(1 - expf(-x), 1/2.2f) * 255 + 0.5f)), and written
+ * as a 24-bit bottom-up BMP with the reference's headers.  Host-only.  The reference's writer tests
+ * its padding array instead of the padding size (:64) and does not compile with g++ 11; rows are
+ * padded to four bytes here.  Negative / NaN radiance (undefined in the reference) maps to 0. */
+int yart_film_tonemap(const float* rgb, size_t n_pixels, uint8_t* bgr_out);
+int yart_film_write_bmp(const char* path, const float* rgb, int32_t width, int32_t height);
+
 /* Per-kernel timing (no counterpart in the reference, which only has a wall-clock
  * Timer around the whole render, include/timer.h:6-26).  While enabled, every
  * intersect call brackets its launches with HIP events on the caller's stream, in three

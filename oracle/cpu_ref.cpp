@@ -679,6 +679,15 @@ void orc_wide_intersect(const void* nodes, const float* rowsA, const float* rows
     });
 }
 
+// Tone map of the reference's bitmap writer (src/bitmap.cpp:8-12), one channel: the expression as
+// the reference writes it.  Parity unpinned -- src/bitmap.cpp does not compile with g++ 11 (:64), so
+// this restatement is all there is to check the product's film output against.
+uint8_t orc_tonemap(float val)
+{
+    static const uint8_t max = 255;
+    return std::min(max, (uint8_t)(std::pow(1 - std::exp(-val), 1.0f / 2.2f) * 255 + 0.5f));
+}
+
 void orc_project(const float* a, const float* b, const float* c, int32_t triIdx, int32_t meshIdx, void* out)
 {
     project(static_cast<TriAccel*>(out), V3{ a[0], a[1], a[2] }, V3{ b[0], b[1], b[2] }, V3{ c[0], c[1], c[2] },

@@ -250,7 +250,18 @@ def reference_load_obj(folder, file, so=None):
     L.ref_obj_counts.argtypes = [c_vp] + [ctypes.POINTER(c_sz)] * 5
     L.ref_obj_get.argtypes = [c_vp] * 7
     L.ref_obj_free.argtypes = [c_vp]
-    h = L.ref_obj_load(os.fsencode(folder), os.fsencode(file))
+    import sys
+    sys.stdout.flush()
+    L.fflush(None)
+    keep, null = os.dup(1), os.open(os.devnull, os.O_WRONLY)
+    os.dup2(null, 1)                    # the reference lists every material and shape on stdout
+    try:
+        h = L.ref_obj_load(os.fsencode(folder), os.fsencode(file))
+        L.fflush(None)
+    finally:
+        os.dup2(keep, 1)
+        os.close(keep)
+        os.close(null)
     n = [c_sz() for _ in range(5)]
     L.ref_obj_counts(h, *[ctypes.byref(x) for x in n])
     nm, nv, nt, ns, nmat = [x.value for x in n]

@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--spp", type=int, default=2)
     ap.add_argument("--verify", action="store_true")
     ap.add_argument("--out", default="")
+    ap.add_argument("--bmp", default="", help="write the gathered frame as a BMP (yart_film_write_bmp)")
     args = ap.parse_args()
 
     import torch
@@ -193,6 +194,9 @@ def main():
                                                                          frame_cpu.view(torch.int32)))
         if args.out:
             np.save(args.out, frame_cpu.numpy())
+        if args.bmp:
+            api.film_write_bmp(args.bmp, frame_cpu.numpy(), args.width, args.height)
+            out["bmp"] = args.bmp
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -39,6 +39,7 @@ EXPORTS = [
     "yart_build_wide_host", "yart_accel_num_wide_nodes", "yart_accel_num_wide_prims", "yart_accel_wide_depth", "yart_accel_get_wide",
     "yart_obj_load", "yart_obj_free", "yart_obj_num_meshes", "yart_obj_num_vertices", "yart_obj_num_triangles",
     "yart_obj_num_materials", "yart_obj_num_spheres", "yart_obj_get", "yart_obj_mesh_name", "yart_obj_material_name",
+    "yart_film_tonemap", "yart_film_write_bmp",
 ]
 
 OBJ_MESH_DTYPE = np.dtype([("first_vertex", np.int32), ("num_vertices", np.int32), ("first_triangle", np.int32),
@@ -99,6 +100,8 @@ def lib():
     for name in ("yart_obj_mesh_name", "yart_obj_material_name"):
         getattr(L, name).argtypes = [_vp, _sz]
         getattr(L, name).restype = ctypes.c_char_p
+    L.yart_film_tonemap.argtypes = [_vp, _sz, _vp]
+    L.yart_film_write_bmp.argtypes = [ctypes.c_char_p, _vp, ctypes.c_int32, ctypes.c_int32]
     L.yart_status_string.argtypes = [ctypes.c_int]
     L.yart_status_string.restype = ctypes.c_char_p
     L.yart_last_error.restype = ctypes.c_char_p
@@ -173,6 +176,20 @@ def load_obj(folder, file):
         return out
     finally:
         L.yart_obj_free(h)
+
+
+def film_tonemap(rgb):
+    """Float r,g,b -> the reference's 8-bit b,g,r (yart_film_tonemap; host-only)."""
+    rgb = np.ascontiguousarray(rgb, np.float32).reshape(-1, 3)
+    out = np.zeros((len(rgb), 3), np.uint8)
+    _check(lib().yart_film_tonemap(_p(rgb), len(rgb), _p(out)))
+    return out
+
+
+def film_write_bmp(path, rgb, width, height):
+    """Float framebuffer [height, width, 3] (row 0 on top) -> 24-bit BMP (yart_film_write_bmp)."""
+    rgb = np.ascontiguousarray(rgb, np.float32).reshape(height, width, 3)
+    _check(lib().yart_film_write_bmp(os.fsencode(path), _p(rgb), width, height))
 
 
 class Accel:

@@ -20,6 +20,11 @@
 #include "wide_build.h"
 #include "obj_ingest.h"
 
+namespace yart {
+void toneMapBgr(const float* rgb, size_t nPixels, uint8_t* bgr);
+bool writeBmp(const char* path, const float* rgb, int32_t width, int32_t height, std::string& err);
+}
+
 namespace {
 
 thread_local std::string g_lastError;
@@ -658,6 +663,22 @@ const char* yart_obj_mesh_name(const YartObjScene* s, size_t i)
 const char* yart_obj_material_name(const YartObjScene* s, size_t i)
 {
     return s && i < s->scene.materials.size() ? s->scene.materials[i].name.c_str() : "";
+}
+
+int yart_film_tonemap(const float* rgb, size_t n_pixels, uint8_t* bgr_out)
+{
+    if (n_pixels && (!rgb || !bgr_out)) return fail(YART_ERR_INVALID_ARGUMENT, "yart_film_tonemap: null argument");
+    yart::toneMapBgr(rgb, n_pixels, bgr_out);
+    return YART_OK;
+}
+
+int yart_film_write_bmp(const char* path, const float* rgb, int32_t width, int32_t height)
+{
+    if (!path || !rgb || width <= 0 || height <= 0 || static_cast<int64_t>(width) * height > (int64_t(1) << 28))
+        return fail(YART_ERR_INVALID_ARGUMENT, "yart_film_write_bmp: null argument or bad size");
+    std::string err;
+    if (!yart::writeBmp(path, rgb, width, height, err)) return fail(YART_ERR_INVALID_ARGUMENT, "yart_film_write_bmp: " + err);
+    return YART_OK;
 }
 
 const char* yart_status_string(int status)
