@@ -77,3 +77,12 @@ def test_shim_reproduces_reference_hitinfo(tmp_path, golden, rule):
         # 4-wide tree: same t bits, see tests/test_gpu_parity.py::assert_within_bar
         same = (prim == golden["prim"]) | (bits(out[:, 1]) == bits(golden["t"]))
         assert same.mean() >= 0.9999 and (prim != golden["prim"]).sum() <= 2
+
+
+def test_worker_pool_under_thread_sanitizer(tmp_path):
+    """The wavefront driver's persistent host threads: 4000 loops, each index exactly once, no race."""
+    exe = str(tmp_path / "test_pool")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", os.path.join(ROOT, "tests", "cxx", "test_pool.cpp"),
+                           "-o", exe, "-lpthread"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, r.stderr[-2000:]

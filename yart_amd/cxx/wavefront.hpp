@@ -20,10 +20,14 @@
 #pragma once
 
 #include <atomic>
+#include <condition_variable>
 #include <cstdint>
+#include <functional>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/yart_amd.h"
@@ -60,10 +64,90 @@ struct WavefrontStats {
     size_t largestBatch = 0;
 };
 
+// Host threads that live as long as the driver: a path-traced frame makes 10^4..10^5 batches, each
+// followed by a parallel loop over its slots, so the threads are started once and woken per loop
+// (the reference starts its 8 workers once per frame as well, src/scheduler.cpp:20-44).
+class WorkerPool {
+public:
+    explicit WorkerPool(int nThreads)
+    {
+        for (int t = 1; t < nThreads; ++t) threads_.emplace_back([this]() { serve(); });
+    }
+    ~WorkerPool()
+    {
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            stop_ = true;
+            ++generation_;
+        }
+        wake_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    WorkerPool(const WorkerPool&) = delete;
+    WorkerPool& operator=(const WorkerPool&) = delete;
+
+    // f(i) for every i in [0, n); returns when all calls have returned.  One loop at a time.
+    template <class F>
+    void parallelFor(size_t n, F&& f)
+    {
+        if (threads_.empty() || n < 64) { for (size_t i = 0; i < n; ++i) f(i); return; }
+        const size_t chunk = n / ((threads_.size() + 1) * 8) + 1;
+        std::atomic<size_t> next{ 0 };
+        std::function<void()> body = [&]() {
+            for (;;) {
+                const size_t b = next.fetch_add(chunk);
+                if (b >= n) return;
+                const size_t e = b + chunk < n ? b + chunk : n;
+                for (size_t i = b; i < e; ++i) f(i);
+            }
+        };
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            body_ = &body;
+            busy_ = threads_.size();
+            ++generation_;
+        }
+        wake_.notify_all();
+        body();
+        std::unique_lock<std::mutex> lock(m_);
+        done_.wait(lock, [this]() { return busy_ == 0; });
+        body_ = nullptr;
+    }
+
+private:
+    void serve()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void()>* body;
+            {
+                std::unique_lock<std::mutex> lock(m_);
+                wake_.wait(lock, [&]() { return generation_ != seen; });
+                seen = generation_;
+                if (stop_) return;
+                body = body_;
+            }
+            (*body)();
+            {
+                std::lock_guard<std::mutex> lock(m_);
+                if (--busy_ == 0) done_.notify_one();
+            }
+        }
+    }
+
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable wake_, done_;
+    const std::function<void()>* body_ = nullptr;
+    uint64_t generation_ = 0;
+    size_t busy_ = 0;
+    bool stop_ = false;
+};
+
 class WavefrontDriver {
 public:
     WavefrontDriver(Engine engine, size_t slots, int hostThreads = 8)
-        : engine_(engine), nSlots_(slots), nThreads_(hostThreads < 1 ? 1 : hostThreads) { }
+        : engine_(engine), nSlots_(slots), pool_(hostThreads < 1 ? 1 : hostThreads) { }
 
     WavefrontStats run(PathIntegrator& integ)
     {
@@ -140,28 +224,11 @@ private:
         if (st != YART_OK) throw std::runtime_error("yart_amd::WavefrontDriver: engine call failed, status " + std::to_string(st));
     }
     template <class F>
-    void parallelFor(size_t n, F&& f) const
-    {
-        if (nThreads_ <= 1 || n < 64) { for (size_t i = 0; i < n; ++i) f(i); return; }
-        std::atomic<size_t> next{ 0 };
-        const size_t chunk = n / (static_cast<size_t>(nThreads_) * 8) + 1;
-        auto body = [&]() {
-            for (;;) {
-                const size_t b = next.fetch_add(chunk);
-                if (b >= n) return;
-                const size_t e = b + chunk < n ? b + chunk : n;
-                for (size_t i = b; i < e; ++i) f(i);
-            }
-        };
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nThreads_; ++t) pool.emplace_back(body);
-        body();
-        for (auto& t : pool) t.join();
-    }
+    void parallelFor(size_t n, F&& f) { pool_.parallelFor(n, std::forward<F>(f)); }
 
     Engine engine_;
     size_t nSlots_;
-    int nThreads_;
+    WorkerPool pool_;
 };
 
 } // namespace yart_amd
