@@ -9,7 +9,9 @@ yart_build_wide_host) checked without a GPU:
 import numpy as np
 import pytest
 
-from conftest import bits
+import os
+
+from conftest import ROOT, bits
 from oracle import oracle as orc
 from yart_amd import api, scenes
 
@@ -142,3 +144,21 @@ def test_degenerate_inputs_build():
     # 21 identical triangles tie exactly; more than fit one of the reference's leaves, so which one it
     # keeps depends on its visiting order -- the t bits are what must agree
     assert got["prim"][0] >= 0 and want["prim"][0] >= 0 and bits(got["t"])[0] == bits(want["t"])[0]
+
+
+def test_builders_do_not_depend_on_thread_count():
+    """Both host builders hand ranges to a thread pool; the arrays must be the same for any pool size."""
+    import hashlib
+    import subprocess
+    import sys
+    code = ("import sys, hashlib; sys.path.insert(0, %r)\n"
+            "from yart_amd import api, scenes\n"
+            "v, t, s = scenes.random_soup(120000, 9000, s=0.01, seed=3)\n"
+            "n, a, b, d = api.build_wide_host(v, t, s)\n"
+            "nodes, ta = api.build_host(v, t)\n"
+            "print(hashlib.sha1(n.tobytes() + a.tobytes() + b.tobytes() + nodes.tobytes() + ta.tobytes()).hexdigest())\n" % ROOT)
+    digests = []
+    for threads in ("1", "3", "8"):
+        env = dict(os.environ, OMP_NUM_THREADS=threads)
+        digests.append(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip())
+    assert len(set(digests)) == 1 and len(digests[0]) == 40, digests

@@ -241,8 +241,8 @@ public:
             setChildren(top.nodes[0], &nodes_[0].box, &ref, 1);
             top.depth = 1;
         } else {
-            jobSpan_ = std::max<uint32_t>(4096u, static_cast<uint32_t>(prims_.size() / (64u * std::max(1u, nThreads))));
-            if (nThreads <= 1) jobSpan_ = 0;             // everything in the top segment
+            // the cut does not depend on the number of threads: the arrays are the same on every machine
+            jobSpan_ = std::max<uint32_t>(4096u, static_cast<uint32_t>(prims_.size() / 1024u));
             emit(0, 1, top, &jobs_);
         }
         // jobs, in parallel
