@@ -203,6 +203,39 @@ int yart_build_wide_host(const float* verts, size_t n_verts, const int32_t* tris
                          void* nodes_out, size_t* n_nodes, void* rows_a_out, void* rows_bc_out,
                          size_t* n_prims, int* depth);
 
+/* ---- Hit post-processing --------------------------------------------------
+ * What the reference derives from a hit before it shades: for a triangle the geometric normal
+ * normal(cross(e1,e2)) and the shading normal n0(1-u-v) + n1 u + n2 v, not normalised
+ * (src/bvhaccel.cpp:283-292, include/triangle.h:158-171); for a sphere normal(orig + dir t - position)
+ * for both (include/sphere.h:79-83).  One record per ray, the float fields of RayHitInfo
+ * (include/vector.h:255-263) in its order, the borrowed Bsdf* / AreaLight* replaced by what
+ * identifies them: for a triangle mesh_idx / tri_idx (Bsdf = the mesh's), for a sphere mesh_idx = -1
+ * and tri_idx = its number in Scene::shapes_, for a miss both -1 and the normals 0.  Bit-identical
+ * to the reference's RayHitInfo for the same hit. */
+typedef struct YartSurface {    /* 48 bytes */
+    float normal[3];
+    float t;
+    float shading_normal[3];
+    float u;
+    float v;
+    int32_t prim;               /* as in YartHit */
+    int32_t mesh_idx;
+    int32_t tri_idx;
+} YartSurface;
+
+/* Uploads what the gather needs: per triangle (leaf order) its geometric normal and its three vertex
+ * normals, per sphere its record.  verts / tris / spheres: the arrays yart_accel_create was given;
+ * vertex_normals: 3 floats per vertex, same numbering as verts (TriangleMesh::normals_ of every
+ * mesh, concatenated).  +64 bytes of HBM per triangle. */
+int yart_accel_set_surface_data(YartAccel* accel, const float* verts, size_t n_verts,
+                                const int32_t* tris, size_t n_tris, const float* vertex_normals,
+                                const float* spheres, size_t n_spheres);
+/* d_rays, d_hits (results of yart_intersect_closest*), d_out: device pointers; asynchronous on `stream`. */
+int yart_surface_dev(YartAccel* accel, const YartRay* d_rays, const YartHit* d_hits, size_t n,
+                     YartSurface* d_out, void* stream);
+/* Host buffers; synchronous. */
+int yart_surface(YartAccel* accel, const YartRay* rays, const YartHit* hits, size_t n, YartSurface* out);
+
 /* ---- Scene ingestion -------------------------------------------------------------
  * Replaces Scene::loadFromObj(folder, file) (src/scene.cpp:159-298) and, beneath it, the bundled
  * tinyobjloader's LoadObj / LoadMtl (external/tinyobjloader/tiny_obj_loader.h:838-1133, :587-813):

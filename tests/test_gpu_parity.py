@@ -214,3 +214,41 @@ def test_wide_tree_walk_on_cpu_agrees_with_kernel(golden, accel):
     occ = orc.wide_intersect(nodes, rows_a, rows_bc, sh, any_hit=True)
     assert np.array_equal(accel.intersect_any(dev(sh), api.YART_RAYS_REGULAR).cpu().numpy(), occ)
     assert np.array_equal(occ, golden["occluded"][ms])
+
+
+def test_concurrent_submissions_on_distinct_streams():
+    """thread-safe for concurrent submissions on distinct streams.  Four host threads, each
+    with its own HIP stream and its own batch, submit closest-hit and any-hit calls at the same time
+    (ctypes drops the GIL for the call); every result must equal the one a serial call gives."""
+    import threading
+    v, t, s = scenes.random_soup(60000, 4000, s=0.02, seed=21)
+    acc = api.Accel(v, t, s)
+    n_threads, rounds = 4, 6
+    batches = [dev(scenes.random_rays(150000 + 7777 * i, seed=100 + i)) for i in range(n_threads)]
+    flag_sets = [api.YART_SORT_RAYS, 0, api.YART_SORT_RAYS | api.YART_REFERENCE_TREE, api.YART_SORT_RAYS]
+    want = [(acc.intersect_closest(b, f).clone(), acc.intersect_any(b, f).clone()) for b, f in zip(batches, flag_sets)]
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(i):
+        try:
+            stream = torch.cuda.Stream()
+            for _ in range(rounds):
+                hits = torch.empty((batches[i].shape[0], 4), dtype=torch.float32, device="cuda")
+                acc.intersect_closest(batches[i], flag_sets[i], out=hits, stream=stream)
+                occ = acc.intersect_any(batches[i], flag_sets[i], stream=stream)
+                stream.synchronize()
+                if not torch.equal(hits.view(torch.int32), want[i][0].view(torch.int32)):
+                    errors.append("thread %d: closest hits differ" % i)
+                if not torch.equal(occ, want[i][1]):
+                    errors.append("thread %d: occlusion differs" % i)
+        except Exception as exc:        # surfaced below; a thread must not die silently
+            errors.append("thread %d: %r" % (i, exc))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(n_threads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    acc.close()
+    assert not errors, errors

@@ -40,7 +40,12 @@ EXPORTS = [
     "yart_obj_load", "yart_obj_free", "yart_obj_num_meshes", "yart_obj_num_vertices", "yart_obj_num_triangles",
     "yart_obj_num_materials", "yart_obj_num_spheres", "yart_obj_get", "yart_obj_mesh_name", "yart_obj_material_name",
     "yart_film_tonemap", "yart_film_write_bmp",
+    "yart_accel_set_surface_data", "yart_surface_dev", "yart_surface",
 ]
+
+SURFACE_DTYPE = np.dtype([("normal", np.float32, 3), ("t", np.float32), ("shading_normal", np.float32, 3),
+                          ("u", np.float32), ("v", np.float32), ("prim", np.int32), ("mesh_idx", np.int32),
+                          ("tri_idx", np.int32)])
 
 OBJ_MESH_DTYPE = np.dtype([("first_vertex", np.int32), ("num_vertices", np.int32), ("first_triangle", np.int32),
                            ("num_triangles", np.int32), ("material", np.int32), ("normals_from_file", np.int32)])
@@ -100,6 +105,9 @@ def lib():
     for name in ("yart_obj_mesh_name", "yart_obj_material_name"):
         getattr(L, name).argtypes = [_vp, _sz]
         getattr(L, name).restype = ctypes.c_char_p
+    L.yart_accel_set_surface_data.argtypes = [_vp, _vp, _sz, _vp, _sz, _vp, _vp, _sz]
+    L.yart_surface_dev.argtypes = [_vp, _vp, _vp, _sz, _vp, _vp]
+    L.yart_surface.argtypes = [_vp, _vp, _vp, _sz, _vp]
     L.yart_film_tonemap.argtypes = [_vp, _sz, _vp]
     L.yart_film_write_bmp.argtypes = [ctypes.c_char_p, _vp, ctypes.c_int32, ctypes.c_int32]
     L.yart_status_string.argtypes = [ctypes.c_int]
@@ -322,6 +330,35 @@ class Accel:
         return out
 
     # -- host buffers (numpy) -----------------------------------------------
+    def set_surface_data(self, verts, tris, vertex_normals, spheres=None):
+        """Upload what hit post-processing needs (yart_accel_set_surface_data)."""
+        verts, tris, spheres = _scene_arrays(verts, tris, spheres)
+        normals = np.ascontiguousarray(vertex_normals, np.float32).reshape(-1, 3)
+        if len(normals) != len(verts):
+            raise YartError("vertex_normals must have one row per vertex")
+        _check(lib().yart_accel_set_surface_data(self._h, _p(verts), len(verts), _p(tris), len(tris), _p(normals),
+                                                 _p(spheres), len(spheres)))
+
+    def surface(self, rays, hits, out=None, stream=None):
+        """rays [n,8], hits [n,4] (device) -> [n,12] float32 device tensor of YartSurface records."""
+        import torch
+        rays = self._rays(rays)
+        n = rays.shape[0]
+        if not (isinstance(hits, torch.Tensor) and hits.is_cuda and hits.is_contiguous() and hits.shape == (n, 4)):
+            raise YartError("hits must be the [n, 4] device tensor of an intersect_closest call")
+        if out is None:
+            out = torch.empty((n, 12), dtype=torch.float32, device=rays.device)
+        _check(lib().yart_surface_dev(self._h, _vp(rays.data_ptr()), _vp(hits.data_ptr()), n, _vp(out.data_ptr()),
+                                      self._stream(stream)))
+        return out
+
+    def surface_host(self, rays, hits):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        hits = np.ascontiguousarray(hits)
+        out = np.zeros(len(rays), SURFACE_DTYPE)
+        _check(lib().yart_surface(self._h, _p(rays), _p(hits), len(rays), _p(out)))
+        return out
+
     def intersect_closest_host(self, rays, flags=0):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
         hits = np.zeros(len(rays), HIT_DTYPE)

@@ -19,6 +19,7 @@
 #include "traverse.h"
 #include "wide_build.h"
 #include "obj_ingest.h"
+#include "task_pool.h"
 
 namespace yart {
 void toneMapBgr(const float* rgb, size_t nPixels, uint8_t* bgr);
@@ -62,6 +63,9 @@ struct YartAccel {
     void* dWideNodes = nullptr;       // the engine's own 4-wide triangle+sphere tree (wide_build.h)
     void* dWideRowsA = nullptr;
     void* dWideRowsBC = nullptr;
+    void* dSurfRows = nullptr;        // hit post-processing (yart_accel_set_surface_data)
+    void* dSurfIds = nullptr;
+    void* dSurfSpheres = nullptr;
     bool hasWide = false;
     size_t wideNodes = 0, widePrims = 0;   // array sizes; the device copy is the only one kept
     int wideDepth = 0;
@@ -356,6 +360,9 @@ void yart_accel_destroy(YartAccel* a)
         (void)hipFree(a->dWideNodes);
         (void)hipFree(a->dWideRowsA);
         (void)hipFree(a->dWideRowsBC);
+        (void)hipFree(a->dSurfRows);
+        (void)hipFree(a->dSurfIds);
+        (void)hipFree(a->dSurfSpheres);
         for (auto& c : a->stagingFree) {
             (void)hipHostFree(c.host);
             (void)hipFree(c.big);
@@ -584,6 +591,88 @@ int yart_accel_profile_read(YartAccel* a, double* ms_sort, double* ms_spheres, d
     if (ms_triangles) *ms_triangles = ms[2];
     if (n_calls) *n_calls = a->profiledCalls;
     a->profiledCalls = 0;
+    return st;
+}
+
+int yart_accel_set_surface_data(YartAccel* a, const float* verts, size_t n_verts, const int32_t* tris, size_t n_tris,
+                                const float* normals, const float* spheres, size_t n_spheres)
+{
+    if (!a) return fail(YART_ERR_INVALID_ARGUMENT, "accel is null");
+    if (n_tris != a->tri.triaccel.size() || n_spheres != a->numSpheres || a->tri.slotOfInput.size() != n_tris)
+        return fail(YART_ERR_INVALID_ARGUMENT, "yart_accel_set_surface_data: not the scene the accel was created from");
+    if ((n_tris && (!verts || !tris || !normals)) || (n_spheres && !spheres))
+        return fail(YART_ERR_INVALID_ARGUMENT, "yart_accel_set_surface_data: null argument");
+    std::vector<float> rows(n_tris * 12);
+    std::vector<int32_t> ids(n_tris * 2);
+    std::atomic<bool> bad{ false };
+    yart::parallelChunks(n_tris, yart::buildThreads(), size_t(1) << 16, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            const int32_t* t = tris + i * 5;
+            for (int c = 0; c < 3; ++c)
+                if (t[c] < 0 || static_cast<size_t>(t[c]) >= n_verts) { bad = true; return; }
+            const float* p0 = verts + static_cast<size_t>(t[0]) * 3;
+            const float* p1 = verts + static_cast<size_t>(t[1]) * 3;
+            const float* p2 = verts + static_cast<size_t>(t[2]) * 3;
+            const float e1[3] = { p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2] };       // include/triangle.h:158-164
+            const float e2[3] = { p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2] };
+            const float cx = e1[1] * e2[2] - e1[2] * e2[1];
+            const float cy = e1[2] * e2[0] - e1[0] * e2[2];
+            const float cz = e1[0] * e2[1] - e1[1] * e2[0];
+            const float inv = 1.0f / std::sqrt(cx * cx + cy * cy + cz * cz);           // include/vector.h:165-168
+            const size_t slot = a->tri.slotOfInput[i];
+            float* r = &rows[slot * 12];
+            r[0] = cx * inv; r[1] = cy * inv; r[2] = cz * inv;
+            for (int c = 0; c < 3; ++c) std::memcpy(r + 3 + c * 3, normals + static_cast<size_t>(t[c]) * 3, 12);
+            ids[slot * 2] = t[3];
+            ids[slot * 2 + 1] = t[4];
+        }
+    });
+    if (bad) return fail(YART_ERR_INVALID_ARGUMENT, "yart_accel_set_surface_data: vertex index out of range");
+    DeviceGuard guard(a->device);
+    if (!guard.ok) return fail(YART_ERR_NO_DEVICE, "hipSetDevice failed");
+    (void)hipFree(a->dSurfRows); (void)hipFree(a->dSurfIds); (void)hipFree(a->dSurfSpheres);
+    a->dSurfRows = a->dSurfIds = a->dSurfSpheres = nullptr;
+    int st = upload(&a->dSurfRows, rows.data(), rows.size() * 4, a->deviceBytes);
+    if (st == YART_OK) st = upload(&a->dSurfIds, ids.data(), ids.size() * 4, a->deviceBytes);
+    if (st == YART_OK) st = upload(&a->dSurfSpheres, spheres, n_spheres * 16, a->deviceBytes);
+    return st;
+}
+
+int yart_surface_dev(YartAccel* a, const YartRay* d_rays, const YartHit* d_hits, size_t n, YartSurface* d_out, void* stream)
+{
+    if (!a) return fail(YART_ERR_INVALID_ARGUMENT, "accel is null");
+    if (n == 0) return YART_OK;
+    if (!d_rays || !d_hits || !d_out) return fail(YART_ERR_INVALID_ARGUMENT, "yart_surface_dev: null argument");
+    if (n > 0xFFFFFFFFull / 2) return fail(YART_ERR_INVALID_ARGUMENT, "yart_surface_dev: batch too large");
+    if ((a->tri.triaccel.size() && !a->dSurfRows) || (a->numSpheres && !a->dSurfSpheres))
+        return fail(YART_ERR_INVALID_ARGUMENT, "yart_surface_dev: call yart_accel_set_surface_data first");
+    DeviceGuard guard(a->device);
+    if (!guard.ok) return fail(YART_ERR_NO_DEVICE, "hipSetDevice failed");
+    const hipError_t e = yart::launchSurface(d_rays, d_hits, static_cast<uint32_t>(n), a->dSurfRows, a->dSurfIds, a->dSurfSpheres,
+                                             d_out, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? YART_OK : failHip(e, "surface kernel");
+}
+
+int yart_surface(YartAccel* a, const YartRay* rays, const YartHit* hits, size_t n, YartSurface* out)
+{
+    if (!a) return fail(YART_ERR_INVALID_ARGUMENT, "accel is null");
+    if (n == 0) return YART_OK;
+    if (!rays || !hits || !out) return fail(YART_ERR_INVALID_ARGUMENT, "yart_surface: null argument");
+    DeviceGuard guard(a->device);
+    if (!guard.ok) return fail(YART_ERR_NO_DEVICE, "hipSetDevice failed");
+    char* block = nullptr;
+    const size_t rayBytes = n * sizeof(YartRay), hitBytes = n * sizeof(YartHit), outBytes = n * sizeof(YartSurface);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&block), rayBytes + hitBytes + outBytes);
+    if (e != hipSuccess) return fail(YART_ERR_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e));
+    int st = YART_OK;
+    if ((e = hipMemcpy(block, rays, rayBytes, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(block + rayBytes, hits, hitBytes, hipMemcpyHostToDevice)) != hipSuccess) st = failHip(e, "hipMemcpy");
+    if (st == YART_OK)
+        st = yart_surface_dev(a, reinterpret_cast<const YartRay*>(block), reinterpret_cast<const YartHit*>(block + rayBytes), n,
+                              reinterpret_cast<YartSurface*>(block + rayBytes + hitBytes), nullptr);
+    if (st == YART_OK && (e = hipMemcpy(out, block + rayBytes + hitBytes, outBytes, hipMemcpyDeviceToHost)) != hipSuccess)
+        st = failHip(e, "hipMemcpy");
+    (void)hipFree(block);
     return st;
 }
 

@@ -1,0 +1,72 @@
+// Hit post-processing on the device: what the reference derives from a hit
+// before shading -- geometric normal and interpolated shading normal of the triangle
+// (src/bvhaccel.cpp:283-292, include/triangle.h:158-171) or the sphere's normal at the hit point
+// (include/sphere.h:79-83) -- for a whole batch, keyed by (prim, u, v) of the hit records.
+//
+// HBM-bound gather: per ray 32 B ray + 16 B hit in, 48 B out, plus one 48-byte surface row per
+// triangle hit (geometric normal precomputed on the host with the reference's expression, three
+// vertex normals) or one 16-byte sphere record.  One ray per lane, no divergence beyond the
+// triangle / sphere / miss split.  Compiled with -ffp-contract=off; sqrt and the division are the
+// correctly rounded IEEE ones, so the bits are the reference's.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "../../include/yart_amd.h"
+#include "traverse.h"
+
+namespace yart {
+namespace {
+
+__global__ __launch_bounds__(256) void surfaceKernel(const float4* __restrict__ rays, const float4* __restrict__ hits,
+                                                     uint32_t n, const float4* __restrict__ rows,
+                                                     const int2* __restrict__ ids, const float4* __restrict__ spheres,
+                                                     float4* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 h = hits[i];
+    const int prim = __float_as_int(h.w);
+    float nx = 0.0f, ny = 0.0f, nz = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    int meshIdx = -1, triIdx = -1;
+    if (prim >= 0) {
+        const float4 r0 = rows[static_cast<size_t>(prim) * 3 + 0];     // geometric normal, n0.x
+        const float4 r1 = rows[static_cast<size_t>(prim) * 3 + 1];     // n0.yz, n1.xy
+        const float4 r2 = rows[static_cast<size_t>(prim) * 3 + 2];     // n1.z, n2.xyz
+        const int2 id = ids[prim];
+        meshIdx = id.x;
+        triIdx = id.y;
+        nx = r0.x; ny = r0.y; nz = r0.z;
+        const float u = h.y, v = h.z;
+        const float w = 1.0f - u - v;                                   // include/triangle.h:168
+        sx = r0.w * w + r1.z * u + r2.y * v;
+        sy = r1.x * w + r1.w * u + r2.z * v;
+        sz = r1.y * w + r2.x * u + r2.w * v;
+    } else if (prim <= -2) {
+        const float4 o = rays[static_cast<size_t>(i) * 2], d = rays[static_cast<size_t>(i) * 2 + 1];
+        const float4 s = spheres[-(prim + 2)];
+        const float t = h.x;
+        const float x = o.x + d.x * t - s.x, y = o.y + d.y * t - s.y, z = o.z + d.z * t - s.z;  // include/sphere.h:80
+        const float inv = 1.0f / sqrtf(x * x + y * y + z * z);       // include/vector.h:165-168; hipcc's default
+        // sqrtf and '/' are the correctly rounded ones (__fsqrt_rn is the NATIVE approximation here)
+        nx = x * inv; ny = y * inv; nz = z * inv;
+        sx = nx; sy = ny; sz = nz;
+        triIdx = -(prim + 2);
+    }
+    out[static_cast<size_t>(i) * 3 + 0] = make_float4(nx, ny, nz, h.x);
+    out[static_cast<size_t>(i) * 3 + 1] = make_float4(sx, sy, sz, h.y);
+    out[static_cast<size_t>(i) * 3 + 2] = make_float4(h.z, h.w, __int_as_float(meshIdx), __int_as_float(triIdx));
+}
+
+} // namespace
+
+hipError_t launchSurface(const void* rays, const void* hits, uint32_t n, const void* rows, const void* ids,
+                         const void* spheres, void* out, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    surfaceKernel<<<(n + 255) / 256, 256, 0, stream>>>(static_cast<const float4*>(rays), static_cast<const float4*>(hits), n,
+                                                      static_cast<const float4*>(rows), static_cast<const int2*>(ids),
+                                                      static_cast<const float4*>(spheres), static_cast<float4*>(out));
+    return hipGetLastError();
+}
+
+} // namespace yart

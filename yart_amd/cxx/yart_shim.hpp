@@ -108,10 +108,12 @@ public:
 
     YartAccel* handle() const { return accel_; }
     const std::vector<YartTriAccel>& triaccel() const { return triaccel_; }
+    bool hasSurfaceData() const { return surface_; }    // normals are derived on the device for batches
 
 private:
     YartAccel* accel_ = nullptr;
     std::vector<YartTriAccel> triaccel_;    // leaf order: prim -> (meshIdx, triIdx)
+    bool surface_ = false;
 };
 
 class Scene {
@@ -192,6 +194,22 @@ public:
     {
         std::vector<YartHit> h(n);
         check(yart_intersect_closest(handle(), reinterpret_cast<const YartRay*>(rays), n, h.data(), flags_));
+        if (accel_->hasSurfaceData() && n >= 256) {     // row K as a device gather (yart_surface)
+            std::vector<YartSurface> s(n);
+            check(yart_surface(handle(), reinterpret_cast<const YartRay*>(rays), h.data(), n, s.data()));
+            for (size_t i = 0; i < n; ++i) {
+                RayHitInfo& o = hits[i];
+                o.normal = Vector3f(s[i].normal[0], s[i].normal[1], s[i].normal[2]);
+                o.shadingNormal = Vector3f(s[i].shading_normal[0], s[i].shading_normal[1], s[i].shading_normal[2]);
+                o.t = s[i].t; o.u = s[i].u; o.v = s[i].v; o.prim = s[i].prim;
+                o.bsdf = nullptr;
+                o.areaLight = nullptr;
+                if (s[i].prim >= 0) o.bsdf = meshes_[s[i].mesh_idx].bsdf;
+                else if (s[i].prim <= -2) { o.bsdf = shapes_[s[i].tri_idx].bsdf; o.areaLight = shapes_[s[i].tri_idx].light; }
+                if (hitFlags) hitFlags[i] = s[i].prim != -1;
+            }
+            return;
+        }
         for (size_t i = 0; i < n; ++i) {
             fill(rays[i], h[i], &hits[i]);
             if (hitFlags) hitFlags[i] = h[i].prim != -1;
@@ -278,6 +296,16 @@ inline BvhAccel::BvhAccel(const Scene& scene, int device)
         throw std::runtime_error(std::string("yart_amd::BvhAccel: ") + yart_status_string(st) + ": " + yart_last_error());
     triaccel_.resize(yart_accel_num_triangles(accel_));
     if (!triaccel_.empty()) yart_accel_get_triaccel(accel_, triaccel_.data());
+    // vertex normals of every mesh -> the device, so that batches get their normals there
+    std::vector<float> nrm;
+    bool complete = true;
+    for (const TriangleMesh& m : scene.getTriangleMeshes()) {
+        complete = complete && m.normals.size() == m.vertices.size();
+        for (const Vector3f& n : m.normals) { nrm.push_back(n.x); nrm.push_back(n.y); nrm.push_back(n.z); }
+    }
+    if (complete)
+        surface_ = yart_accel_set_surface_data(accel_, verts.data(), verts.size() / 3, tris.data(), tris.size() / 5, nrm.data(),
+                                               sph.data(), sph.size() / 4) == YART_OK;
 }
 
 } // namespace yart_amd
