@@ -64,7 +64,6 @@ struct YartAccel {
     void* dWideRowsA = nullptr;
     void* dWideRowsBC = nullptr;
     void* dSurfRows = nullptr;        // hit post-processing (yart_accel_set_surface_data)
-    void* dSurfIds = nullptr;
     void* dSurfSpheres = nullptr;
     bool hasWide = false;
     size_t wideNodes = 0, widePrims = 0;   // array sizes; the device copy is the only one kept
@@ -361,7 +360,6 @@ void yart_accel_destroy(YartAccel* a)
         (void)hipFree(a->dWideRowsA);
         (void)hipFree(a->dWideRowsBC);
         (void)hipFree(a->dSurfRows);
-        (void)hipFree(a->dSurfIds);
         (void)hipFree(a->dSurfSpheres);
         for (auto& c : a->stagingFree) {
             (void)hipHostFree(c.host);
@@ -602,8 +600,7 @@ int yart_accel_set_surface_data(YartAccel* a, const float* verts, size_t n_verts
         return fail(YART_ERR_INVALID_ARGUMENT, "yart_accel_set_surface_data: not the scene the accel was created from");
     if ((n_tris && (!verts || !tris || !normals)) || (n_spheres && !spheres))
         return fail(YART_ERR_INVALID_ARGUMENT, "yart_accel_set_surface_data: null argument");
-    std::vector<float> rows(n_tris * 12);
-    std::vector<int32_t> ids(n_tris * 2);
+    std::vector<float> rows(n_tris * 16);       // one 64-byte line per triangle
     std::atomic<bool> bad{ false };
     yart::parallelChunks(n_tris, yart::buildThreads(), size_t(1) << 16, [&](size_t b, size_t e) {
         for (size_t i = b; i < e; ++i) {
@@ -620,20 +617,19 @@ int yart_accel_set_surface_data(YartAccel* a, const float* verts, size_t n_verts
             const float cz = e1[0] * e2[1] - e1[1] * e2[0];
             const float inv = 1.0f / std::sqrt(cx * cx + cy * cy + cz * cz);           // include/vector.h:165-168
             const size_t slot = a->tri.slotOfInput[i];
-            float* r = &rows[slot * 12];
+            float* r = &rows[slot * 16];
             r[0] = cx * inv; r[1] = cy * inv; r[2] = cz * inv;
             for (int c = 0; c < 3; ++c) std::memcpy(r + 3 + c * 3, normals + static_cast<size_t>(t[c]) * 3, 12);
-            ids[slot * 2] = t[3];
-            ids[slot * 2 + 1] = t[4];
+            std::memcpy(r + 12, t + 3, 8);      // meshIdx, triIdx
+            r[14] = r[15] = 0.0f;
         }
     });
     if (bad) return fail(YART_ERR_INVALID_ARGUMENT, "yart_accel_set_surface_data: vertex index out of range");
     DeviceGuard guard(a->device);
     if (!guard.ok) return fail(YART_ERR_NO_DEVICE, "hipSetDevice failed");
-    (void)hipFree(a->dSurfRows); (void)hipFree(a->dSurfIds); (void)hipFree(a->dSurfSpheres);
-    a->dSurfRows = a->dSurfIds = a->dSurfSpheres = nullptr;
+    (void)hipFree(a->dSurfRows); (void)hipFree(a->dSurfSpheres);
+    a->dSurfRows = a->dSurfSpheres = nullptr;
     int st = upload(&a->dSurfRows, rows.data(), rows.size() * 4, a->deviceBytes);
-    if (st == YART_OK) st = upload(&a->dSurfIds, ids.data(), ids.size() * 4, a->deviceBytes);
     if (st == YART_OK) st = upload(&a->dSurfSpheres, spheres, n_spheres * 16, a->deviceBytes);
     return st;
 }
@@ -648,7 +644,7 @@ int yart_surface_dev(YartAccel* a, const YartRay* d_rays, const YartHit* d_hits,
         return fail(YART_ERR_INVALID_ARGUMENT, "yart_surface_dev: call yart_accel_set_surface_data first");
     DeviceGuard guard(a->device);
     if (!guard.ok) return fail(YART_ERR_NO_DEVICE, "hipSetDevice failed");
-    const hipError_t e = yart::launchSurface(d_rays, d_hits, static_cast<uint32_t>(n), a->dSurfRows, a->dSurfIds, a->dSurfSpheres,
+    const hipError_t e = yart::launchSurface(d_rays, d_hits, static_cast<uint32_t>(n), a->dSurfRows, a->dSurfSpheres,
                                              d_out, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? YART_OK : failHip(e, "surface kernel");
 }

@@ -3,9 +3,9 @@
 // (src/bvhaccel.cpp:283-292, include/triangle.h:158-171) or the sphere's normal at the hit point
 // (include/sphere.h:79-83) -- for a whole batch, keyed by (prim, u, v) of the hit records.
 //
-// HBM-bound gather: per ray 32 B ray + 16 B hit in, 48 B out, plus one 48-byte surface row per
+// HBM-bound gather: per ray 16 B hit in, 48 B out, plus one 64-byte surface row = one line per
 // triangle hit (geometric normal precomputed on the host with the reference's expression, three
-// vertex normals) or one 16-byte sphere record.  One ray per lane, no divergence beyond the
+// vertex normals, meshIdx, triIdx) or the 32-B ray + one 16-byte sphere record per sphere hit.  One ray per lane, no divergence beyond the
 // triangle / sphere / miss split.  Compiled with -ffp-contract=off; sqrt and the division are the
 // correctly rounded IEEE ones, so the bits are the reference's.
 #include <hip/hip_runtime.h>
@@ -19,7 +19,7 @@ namespace {
 
 __global__ __launch_bounds__(256) void surfaceKernel(const float4* __restrict__ rays, const float4* __restrict__ hits,
                                                      uint32_t n, const float4* __restrict__ rows,
-                                                     const int2* __restrict__ ids, const float4* __restrict__ spheres,
+                                                     const float4* __restrict__ spheres,
                                                      float4* __restrict__ out)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -29,12 +29,12 @@ __global__ __launch_bounds__(256) void surfaceKernel(const float4* __restrict__ 
     float nx = 0.0f, ny = 0.0f, nz = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
     int meshIdx = -1, triIdx = -1;
     if (prim >= 0) {
-        const float4 r0 = rows[static_cast<size_t>(prim) * 3 + 0];     // geometric normal, n0.x
-        const float4 r1 = rows[static_cast<size_t>(prim) * 3 + 1];     // n0.yz, n1.xy
-        const float4 r2 = rows[static_cast<size_t>(prim) * 3 + 2];     // n1.z, n2.xyz
-        const int2 id = ids[prim];
-        meshIdx = id.x;
-        triIdx = id.y;
+        const float4 r0 = rows[static_cast<size_t>(prim) * 4 + 0];     // geometric normal, n0.x
+        const float4 r1 = rows[static_cast<size_t>(prim) * 4 + 1];     // n0.yz, n1.xy
+        const float4 r2 = rows[static_cast<size_t>(prim) * 4 + 2];     // n1.z, n2.xyz
+        const float4 r3 = rows[static_cast<size_t>(prim) * 4 + 3];     // meshIdx, triIdx
+        meshIdx = __float_as_int(r3.x);
+        triIdx = __float_as_int(r3.y);
         nx = r0.x; ny = r0.y; nz = r0.z;
         const float u = h.y, v = h.z;
         const float w = 1.0f - u - v;                                   // include/triangle.h:168
@@ -59,12 +59,12 @@ __global__ __launch_bounds__(256) void surfaceKernel(const float4* __restrict__ 
 
 } // namespace
 
-hipError_t launchSurface(const void* rays, const void* hits, uint32_t n, const void* rows, const void* ids,
+hipError_t launchSurface(const void* rays, const void* hits, uint32_t n, const void* rows,
                          const void* spheres, void* out, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
     surfaceKernel<<<(n + 255) / 256, 256, 0, stream>>>(static_cast<const float4*>(rays), static_cast<const float4*>(hits), n,
-                                                      static_cast<const float4*>(rows), static_cast<const int2*>(ids),
+                                                      static_cast<const float4*>(rows),
                                                       static_cast<const float4*>(spheres), static_cast<float4*>(out));
     return hipGetLastError();
 }

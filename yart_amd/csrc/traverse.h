@@ -73,9 +73,9 @@ hipError_t sortRays(const float4* rays, uint32_t n, const float lo[3], const flo
                     uint32_t gridBits, uint32_t* perm, void* workspace, size_t workspaceBytes, hipStream_t stream);
 size_t sortWorkspaceBytes(uint32_t n);
 
-// Hit post-processing (surface.hip): rows = 48 B per triangle in leaf-slot order (geometric normal + the three
-// vertex normals), ids = (meshIdx, triIdx) per leaf slot, spheres = cx,cy,cz,r in the scene's order.
-hipError_t launchSurface(const void* rays, const void* hits, uint32_t n, const void* rows, const void* ids,
+// Hit post-processing (surface.hip): rows = 64 B per triangle in leaf-slot order (geometric normal, the three
+// vertex normals, meshIdx, triIdx, 8 B unused), spheres = cx,cy,cz,r in the scene's order.
+hipError_t launchSurface(const void* rays, const void* hits, uint32_t n, const void* rows,
                          const void* spheres, void* out, hipStream_t stream);
 
 } // namespace yart
