@@ -85,8 +85,10 @@ enum yart_flags {
     /* Launch one lane per ray over a plain grid instead of the persistent
      * work-pulling kernel (A/B measurements). */
     YART_STATIC_LAUNCH  = 1u << 1,
-    /* Sort the batch by a Morton key of origin + direction octant before
-     * traversal (results are written back in the caller's order). */
+    /* The batch is incoherent: sort it by a Morton key of origin + direction octant before
+     * traversal when that pays -- batches of at least YART_SORT_MIN_RAYS rays (environment, read
+     * at create; default 1572864: measured crossover on a scene far larger than L2).  Results are
+     * written back in the caller's order either way. */
     YART_SORT_RAYS      = 1u << 2,
     /* Distance-pruned traversal of the REFERENCE's binary tree (sphere-tree pass, then the
      * triangle tree, like include/scene.h:142-146) instead of the engine's own 4-wide

@@ -252,3 +252,25 @@ def test_concurrent_submissions_on_distinct_streams():
         th.join()
     acc.close()
     assert not errors, errors
+
+
+def test_sort_threshold_is_a_pure_performance_policy(monkeypatch):
+    """With the default YART_SORT_MIN_RAYS a small batch is not sorted, a large one is; results are the
+    same as with the threshold lifted (sorting never changes an answer)."""
+    v, t, s = scenes.random_soup(50000, 3000, s=0.02, seed=8)
+    rays = dev(scenes.random_rays(1 << 21, seed=9))
+    forced = api.Accel(v, t, s)                                # conftest: threshold 0
+    monkeypatch.delenv("YART_SORT_MIN_RAYS")
+    default = api.Accel(v, t, s)
+    for n in (1000, 1 << 21):
+        default.profile(True)
+        default.profile_read()
+        a = default.intersect_closest(rays[:n], api.YART_SORT_RAYS)
+        torch.cuda.synchronize()
+        sorted_ms = default.profile_read()["ms_sort"]
+        default.profile(False)
+        assert (sorted_ms > 0) == (n >= (3 << 19))
+        b = forced.intersect_closest(rays[:n], api.YART_SORT_RAYS)
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    forced.close()
+    default.close()

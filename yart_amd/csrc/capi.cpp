@@ -78,6 +78,7 @@ struct YartAccel {
     // scheduling knobs of the persistent kernel (YART_REFILL_MIN / YART_NODE_MIN override)
     uint32_t refillMin = 16, nodeMin = 24;                    // reference-tree kernels
     uint32_t wideRefillMin = 16, wideNodeMin = 40, wideChunk = 64, wideBlocksPerCU = 0;   // wide-tree kernel
+    uint32_t sortMinRays = 3u << 19;   // below ~1.5 M rays the sort costs more than it saves (profiles/r01_batch_sweep.jsonl)
     uint32_t sortOctShift = 0, sortGridBits = 7;      // 7: 24-bit keys = 3 radix passes; finer grids measured no better
     // Small host-buffer calls (the one-ray-per-call pattern of the reference's renderer,
     // src/renderer.cpp:59,104): a pool of { stream, pinned host block the kernels read and
@@ -169,7 +170,7 @@ int run(YartAccel* a, const Launch& L)
 
     uint32_t* perm = nullptr;
     void* sortWs = nullptr;
-    if (L.flags & YART_SORT_RAYS) {
+    if ((L.flags & YART_SORT_RAYS) && n >= a->sortMinRays) {
         const size_t wsBytes = yart::sortWorkspaceBytes(n);
         const size_t permBytes = (static_cast<size_t>(n) * 4 + 255) & ~size_t(255);
         hipError_t e = hipMallocAsync(&sortWs, wsBytes + permBytes, L.stream);
@@ -275,6 +276,7 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
     if (a->wideNodeMin < 1) a->wideNodeMin = 1;
     if (a->wideNodeMin > 64) a->wideNodeMin = 64;
     if (const char* v = std::getenv("YART_SORT_GRID_BITS")) a->sortGridBits = static_cast<uint32_t>(std::atoi(v));
+    if (const char* v = std::getenv("YART_SORT_MIN_RAYS")) a->sortMinRays = static_cast<uint32_t>(std::strtoul(v, nullptr, 10));
     if (const char* v = std::getenv("YART_SORT_OCT_SHIFT")) a->sortOctShift = static_cast<uint32_t>(std::atoi(v));
     if (const char* v = std::getenv("YART_WIDE_BLOCKS_PER_CU")) a->wideBlocksPerCU = static_cast<uint32_t>(std::atoi(v));
     if (const char* v = std::getenv("YART_WIDE_CHUNK")) a->wideChunk = static_cast<uint32_t>(std::atoi(v));
