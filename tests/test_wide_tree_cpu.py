@@ -162,3 +162,27 @@ def test_builders_do_not_depend_on_thread_count():
         env = dict(os.environ, OMP_NUM_THREADS=threads)
         digests.append(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip())
     assert len(set(digests)) == 1 and len(digests[0]) == 40, digests
+
+
+def test_scene_with_non_finite_vertices():
+    """tests/golden/obj/syntax.obj has a vertex at +inf and a denormal: both builders must cope (the
+    reference's does), the reference tree stays bit-identical, the wide tree answers like the reference
+    (exact-t ties between its duplicated triangles aside)."""
+    o = api.load_obj(os.path.join(ROOT, "tests", "golden", "obj") + os.sep, "syntax.obj")
+    assert not np.isfinite(o["verts"]).all()
+    nodes, ta = api.build_host(o["verts"], o["tris"])
+    ref = orc.Oracle(o["verts"], o["tris"], o["spheres"])
+    assert nodes.tobytes() == ref.nodes().tobytes()
+    assert np.array_equal(bits(ta.view(np.float32)), bits(ref.triaccel().view(np.float32)))
+    n, a, b, _ = api.build_wide_host(o["verts"], o["tris"], o["spheres"])
+    rng = np.random.default_rng(2)
+    rays = np.zeros((20000, 8), np.float32)
+    rays[:, 0:3] = rng.uniform(-3, 9, (20000, 3))
+    d = rng.normal(size=(20000, 3))
+    rays[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays[:, 7] = np.inf
+    want = ref.intersect(rays)
+    got = orc.wide_intersect(n, a, b, rays)
+    assert (want["prim"] != -1).sum() > 1000
+    assert np.array_equal(bits(got["t"]), bits(want["t"]))
+    assert (got["prim"] == want["prim"]).mean() >= 0.9999
