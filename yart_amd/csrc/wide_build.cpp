@@ -55,6 +55,11 @@ struct BNode {                          // trivially constructible: the pool bel
     uint32_t left, right;               // interior (count == 0)
     uint32_t begin, count;              // leaf: prims[begin, begin + count), one kind
     uint32_t span;                      // primitives below this node (any node)
+    // collapse plan (planCollapse): cost[i-1] = least total area of the wide nodes needed to hang this
+    // subtree into at most i slots of a parent; take[i-1] = how many of those slots the left child
+    // gets, 0 = the subtree becomes one wide node of its own; take[0] = the split when it does
+    float cost[4];
+    uint8_t take[4];
 };
 
 struct BNodePool {                      // 2N+2 nodes of address space; only the pages a build touches are committed
@@ -81,6 +86,42 @@ public:
         pool_.run(nThreads, Job{ 0u, 0u, static_cast<uint32_t>(prims_.size()) },
                   [this](const Job& j) { build(j.node, j.begin, j.end, true); });
         nodes_.used = next_;
+    }
+
+    // Which binary nodes become wide nodes.  Opening the child of largest area until four slots are
+    // full (the usual greedy collapse) leaves 36 % of the nodes of a single-primitive-leaf tree with
+    // two children; the cost of a traversal step does not depend on how many slots are used, so
+    // the plan minimises the summed area (= expected visits) of the wide nodes instead: a dynamic
+    // programme over (node, slots available), bottom-up.  Children are always allocated after their
+    // parent, so descending index order is a valid bottom-up order.
+    void planCollapse()
+    {
+        for (size_t idx = nodes_.used; idx-- > 0;) {
+            BNode& n = nodes_[idx];
+            if (n.count > 0) {
+                for (int i = 0; i < 4; ++i) { n.cost[i] = 0.0f; n.take[i] = 0; }
+                continue;
+            }
+            const BNode& l = nodes_[n.left];
+            const BNode& r = nodes_[n.right];
+            float forest[5];
+            uint8_t split[5];
+            for (int k = 2; k <= 4; ++k) {
+                forest[k] = std::numeric_limits<float>::infinity();
+                split[k] = 1;
+                for (int j = 1; j < k; ++j) {
+                    const float c = l.cost[j - 1] + r.cost[k - j - 1];
+                    if (c < forest[k]) { forest[k] = c; split[k] = static_cast<uint8_t>(j); }
+                }
+            }
+            const float asNode = n.box.halfArea() + forest[4];
+            n.cost[0] = asNode;
+            n.take[0] = split[4];
+            for (int k = 2; k <= 4; ++k) {
+                if (forest[k] < asNode) { n.cost[k - 1] = forest[k]; n.take[k - 1] = split[k]; }
+                else { n.cost[k - 1] = asNode; n.take[k - 1] = 0; }
+            }
+        }
     }
 
     BNodePool& nodes() { return nodes_; }
@@ -219,6 +260,7 @@ public:
         : nodes_(nodes), prims_(prims), tri_(tri), spheres_(spheres), out_(out) { }
 
     bool tooManyPrims = false;
+    bool planned_ = false;              // follow BNode::take (planCollapse) instead of the greedy collapse
 
     void run(unsigned nThreads)
     {
@@ -373,18 +415,25 @@ private:
         sg.depth = std::max(sg.depth, depth);
         uint32_t kids[4] = { nodes_[bnode].left, nodes_[bnode].right, 0, 0 };
         int n = 2;
-        while (n < 4) {                                  // open the largest interior child
-            int best = -1;
-            float bestArea = -1.0f;
-            for (int i = 0; i < n; ++i) {
-                if (nodes_[kids[i]].count > 0) continue;
-                const float a = nodes_[kids[i]].box.halfArea();
-                if (a > bestArea) { bestArea = a; best = i; }
+        if (planned_) {                                  // the slots go where planCollapse put them
+            n = 0;
+            const int leftSlots = nodes_[bnode].take[0];
+            gather(nodes_[bnode].left, leftSlots, kids, n);
+            gather(nodes_[bnode].right, 4 - leftSlots, kids, n);
+        } else {
+            while (n < 4) {                              // open the largest interior child
+                int best = -1;
+                float bestArea = -1.0f;
+                for (int i = 0; i < n; ++i) {
+                    if (nodes_[kids[i]].count > 0) continue;
+                    const float a = nodes_[kids[i]].box.halfArea();
+                    if (a > bestArea) { bestArea = a; best = i; }
+                }
+                if (best < 0) break;
+                const uint32_t open = kids[best];
+                kids[best] = nodes_[open].left;
+                kids[n++] = nodes_[open].right;
             }
-            if (best < 0) break;
-            const uint32_t open = kids[best];
-            kids[best] = nodes_[open].left;
-            kids[n++] = nodes_[open].right;
         }
         const uint32_t idx = static_cast<uint32_t>(sg.nodes.size());
         sg.nodes.emplace_back();
@@ -401,6 +450,16 @@ private:
         }
         setChildren(sg.nodes[idx], boxes, refs, n);
         return idx;
+    }
+
+    // the binary nodes that fill `slots` slots of a parent for the subtree at `b`
+    void gather(uint32_t b, int slots, uint32_t* kids, int& n) const
+    {
+        const BNode& node = nodes_[b];
+        if (node.count > 0 || slots == 1 || node.take[slots - 1] == 0) { kids[n++] = b; return; }
+        const int leftSlots = node.take[slots - 1];
+        gather(node.left, leftSlots, kids, n);
+        gather(node.right, slots - leftSlots, kids, n);
     }
 
     uint32_t leaf(const BNode& n, Segment& sg)
@@ -497,8 +556,12 @@ int buildWideBvh(const float* verts, size_t nVerts, const int32_t* tris, size_t 
         const double t0 = now();
         BinaryBuilder b(prims, maxLeaf, attempt == 1);
         if (!prims.empty()) b.run();
+        const char* greedy = std::getenv("YART_WIDE_GREEDY_COLLAPSE");
+        const bool plan = !(greedy && greedy[0] == '1');
+        if (plan && !prims.empty()) b.planCollapse();
         const double t1 = now();
         Emitter e(b.nodes(), prims, tri, spheres, out);
+        e.planned_ = plan;
         e.run(prims.size() < kSpawnAbove ? 1u : buildThreads());
         if (timing) fprintf(stderr, "wide build: binary SAH %.2fs, collapse+emit %.2fs (%zu nodes, depth %d)\n", t1 - t0, now() - t1, out.nodes.size(), out.depth);
         if (e.tooManyPrims) {
