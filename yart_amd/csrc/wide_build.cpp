@@ -21,9 +21,9 @@ namespace yart {
 namespace {
 
 constexpr uint32_t kSphereId = 0x80000000u;
-constexpr int kBins = 16;
+constexpr int kMaxBins = 64;
+int envInt(const char* name, int dflt) { const char* v = std::getenv(name); return v ? std::atoi(v) : dflt; }
 constexpr uint32_t kSpawnAbove = 1u << 15;      // ranges larger than this are split off as pool jobs
-constexpr uint32_t kOneAxisAbove = 1u << 20;    // very large ranges: bin the widest axis only
 
 struct Box {
     float lo[3], hi[3];
@@ -190,27 +190,28 @@ private:
             return begin + count / 2;                    // all centroids coincide (or are not finite)
         if (medianOnly_) return median(begin, end, widest);
 
+        const int nBins = count > static_cast<uint32_t>(fineBinsBelow_) ? bins_ : fineBins_;
         int bestAxis = -1, bestSplit = 0;
         float bestCost = std::numeric_limits<float>::infinity();
         for (int a = 0; a < 3; ++a) {
-            if (count > kOneAxisAbove && a != widest) continue;
+            if (count > oneAxisAbove_ && a != widest) continue;
             if (!(ext[a] > 0.0f)) continue;
-            Box bins[kBins];
-            uint32_t cnt[kBins] = { 0 };
+            Box bins[kMaxBins];
+            uint32_t cnt[kMaxBins] = { 0 };
             for (auto& b : bins) b.reset();
-            const float scale = static_cast<float>(kBins) / ext[a];
+            const float scale = static_cast<float>(nBins) / ext[a];
             for (uint32_t i = begin; i < end; ++i) {
                 int b = static_cast<int>((prims_[i].c[a] - cbox.lo[a]) * scale);
-                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                b = b < 0 ? 0 : (b >= nBins ? nBins - 1 : b);
                 bins[b].grow(prims_[i].lo, prims_[i].hi);
                 ++cnt[b];
             }
-            float rightArea[kBins];
-            uint32_t rightCnt[kBins];
+            float rightArea[kMaxBins];
+            uint32_t rightCnt[kMaxBins];
             Box acc;
             acc.reset();
             uint32_t c = 0;
-            for (int b = kBins - 1; b > 0; --b) {
+            for (int b = nBins - 1; b > 0; --b) {
                 acc.grow(bins[b]);
                 c += cnt[b];
                 rightArea[b] = acc.halfArea();
@@ -218,7 +219,7 @@ private:
             }
             acc.reset();
             c = 0;
-            for (int b = 1; b < kBins; ++b) {             // split s: bins [0,s) left, [s,kBins) right
+            for (int b = 1; b < nBins; ++b) {             // split s: bins [0,s) left, [s,nBins) right
                 acc.grow(bins[b - 1]);
                 c += cnt[b - 1];
                 if (c == 0 || rightCnt[b] == 0) continue;
@@ -227,11 +228,11 @@ private:
             }
         }
         if (bestAxis < 0) return median(begin, end, widest);
-        const float lo = cbox.lo[bestAxis], scale = static_cast<float>(kBins) / ext[bestAxis];
+        const float lo = cbox.lo[bestAxis], scale = static_cast<float>(nBins) / ext[bestAxis];
         const int s = bestSplit, axis = bestAxis;
         auto m = std::partition(prims_.begin() + begin, prims_.begin() + end, [=](const BPrim& p) {
             int b = static_cast<int>((p.c[axis] - lo) * scale);
-            b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+            b = b < 0 ? 0 : (b >= nBins ? nBins - 1 : b);
             return b < s;
         });
         const uint32_t mid = static_cast<uint32_t>(m - prims_.begin());
@@ -244,6 +245,11 @@ private:
     std::atomic<uint32_t> next_{ 1 };
     int maxLeaf_;
     bool medianOnly_;
+    // SAH binning: bins per axis, all three axes below oneAxisAbove_ primitives (the widest only above)
+    int bins_ = std::max(2, std::min(kMaxBins, envInt("YART_SAH_BINS", 16)));
+    int fineBins_ = std::max(2, std::min(kMaxBins, envInt("YART_SAH_FINE_BINS", 16)));
+    int fineBinsBelow_ = envInt("YART_SAH_FINE_BELOW", 0);
+    uint32_t oneAxisAbove_ = static_cast<uint32_t>(envInt("YART_SAH_ONE_AXIS_ABOVE", 1 << 20));
     TaskPool<Job> pool_;
 };
 
