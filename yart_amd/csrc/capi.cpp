@@ -42,7 +42,7 @@ int failHip(hipError_t e, const char* what)
     return YART_ERR_HIP;
 }
 
-constexpr int kCounterSlots = 64;     // 256-byte work-counter slots, handed out round-robin
+constexpr int kCounterSlots = 1024;   // 256-byte work-counter slots, handed out round-robin: a slot is reused only after 1023 later launches
 
 } // namespace
 
