@@ -70,13 +70,27 @@ def main():
     ap.add_argument("--spp", type=int, default=4)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--obj", nargs=2, metavar=("FOLDER", "FILE"), default=None,
+                    help="trace this OBJ scene (loaded by yart_obj_load, e.g. a supplied Sponza) instead of the stand-in; "
+                         "camera and light are placed from its bounds")
     args = ap.parse_args()
 
     import torch
     from yart_amd import api, scenes
     from oracle import oracle as orc
 
-    verts, tris, sph = scenes.architectural(args.tris, seed=args.seed)
+    cam_pos, cam_dir, light_pos, label = [-10.0, 5.0, 0.0], [1.0, -0.1, 0.05], [0.0, 9.0, 0.0], "Sponza-class stand-in"
+    if args.obj:
+        o = api.load_obj(args.obj[0] if args.obj[0].endswith(os.sep) else args.obj[0] + os.sep, args.obj[1])
+        verts, tris, sph = o["verts"], o["tris"], o["spheres"]
+        finite = verts[np.isfinite(verts).all(1)]
+        lo, hi = finite.min(0), finite.max(0)
+        c, e = (lo + hi) / 2, hi - lo
+        cam_pos = [float(c[0] - 0.4 * e[0]), float(c[1] + 0.1 * e[1]), float(c[2])]
+        light_pos = [float(c[0]), float(c[1] + 0.4 * e[1]), float(c[2])]
+        label = "OBJ %s" % args.obj[1]
+    else:
+        verts, tris, sph = scenes.architectural(args.tris, seed=args.seed)
     t0 = time.time()
     acc = api.Accel(verts, tris, sph, device=0)
     build_s = time.time() - t0
@@ -87,10 +101,9 @@ def main():
              "device_MB": round(acc.device_bytes / 1e6, 1), "build_s": round(build_s, 2)}
 
     # ---- C2: primary rays
-    cam_pos, cam_dir = [-10.0, 5.0, 0.0], [1.0, -0.1, 0.05]
     rays_np = scenes.camera_rays(cam_pos, cam_dir, args.width, args.height, 0.785398)
     d_rays = torch.from_numpy(rays_np).cuda()
-    out = {"config": "C2 primary rays %dx%d, Sponza-class stand-in (%d tris)" % (args.width, args.height, acc.num_triangles),
+    out = {"config": "C2 primary rays %dx%d, %s (%d tris)" % (args.width, args.height, label, acc.num_triangles),
            "scene": scene, "rays": len(rays_np)}
     for name, flags in (("default", 0), ("sorted", api.YART_SORT_RAYS), ("reference_tree", api.YART_REFERENCE_TREE),
                         ("reference_rule", api.YART_REFERENCE_RULE)):
@@ -111,7 +124,7 @@ def main():
     px = np.tile(xs.ravel(), spp) + (np.random.RandomState(5).random_sample(W * H * spp).astype(np.float32) - 0.5)
     py = np.tile(ys.ravel(), spp) + (np.random.RandomState(6).random_sample(W * H * spp).astype(np.float32) - 0.5)
     rays = torch.from_numpy(scenes.camera_rays(cam_pos, cam_dir, W, H, 0.785398, px, py)).cuda()
-    light = torch.tensor([0.0, 9.0, 0.0], device="cuda")
+    light = torch.tensor(light_pos, device="cuda")
     bounces = []
     for b in range(args.depth):
         n = rays.shape[0]
