@@ -69,6 +69,14 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise YartError("%s not found: build it with `make -C yart_amd/csrc` "
                         "(or __graft_entry__.build()); there is no fallback path" % LIB_PATH)
+    # One HIP runtime per process: PyTorch ships its own libamdhip64 and this binding hands torch's
+    # device buffers and streams to the library, so torch's copy has to be the one both use.  Loading
+    # the library first would bring in /opt/rocm's copy as a second runtime, and the one initialised
+    # second finds no device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     L.yart_accel_create.argtypes = [_vp, _sz, _vp, _sz, _vp, _sz, ctypes.c_int, ctypes.POINTER(_vp)]
     L.yart_accel_destroy.argtypes = [_vp]
