@@ -223,20 +223,20 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
                 rf[2] = __float_as_uint(q3.z); rf[3] = __float_as_uint(q3.w);
                 bool h[4];
                 slab4(q0, q1, q2, r, bound, tn, h);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) h[c] = h[c] && rf[c] != kWideNone;
+                // an unused slot needs no test of its own: its box is inverted on every axis (qlo 255, qhi 0:
+                // wide_build.cpp clear()), so it exits before it enters
                 if (COUNT) cNodes += 4;
                 {
-                    // nearest child next, the others pushed far to near
-                    const float big = 3.0e38f;
+                    // nearest child next, the others pushed far to near.  A hit child has tn < tmax, so
+                    // +inf marks the missed ones and sorts them last.
+                    const float inf = __builtin_inff();
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) tn[c] = h[c] ? fminf(tn[c], big) : __builtin_inff();
-                    const int nHit = (int)h[0] + (int)h[1] + (int)h[2] + (int)h[3];
+                    for (int c = 0; c < 4; ++c) tn[c] = h[c] ? tn[c] : inf;
                     YART_CSWAP(0, 1) YART_CSWAP(2, 3) YART_CSWAP(0, 2) YART_CSWAP(1, 3) YART_CSWAP(1, 2)
-                    if (nHit > 3) push(rf[3]);
-                    if (nHit > 2) push(rf[2]);
-                    if (nHit > 1) push(rf[1]);
-                    cur = (nHit > 0) ? rf[0] : pop();
+                    if (tn[3] < inf) push(rf[3]);
+                    if (tn[2] < inf) push(rf[2]);
+                    if (tn[1] < inf) push(rf[1]);
+                    cur = (tn[0] < inf) ? rf[0] : pop();
                 }
             }
         }
