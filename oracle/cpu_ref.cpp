@@ -468,8 +468,8 @@ bool traverseWide(const WideNodeRec* nodes, const float* rowsA, const float* row
                     tNear = std::fmax(tNear, std::fma(qn, B, A));
                     tFar = std::fmin(tFar, std::fma(qf, B, A));
                 }
-                const bool h = !(tFar < tNear) && (tFar > 0.0f) && (tNear < r.tmax) && n.ref[ch] != kNone;
-                tn[ch] = h ? std::fmin(tNear, 3.0e38f) : inf;
+                const bool h = !(tFar < tNear) && tNear < inf && n.ref[ch] != kNone;     // as traverse_wide.hip slab4 + its +inf marker
+                tn[ch] = h ? tNear : inf;
                 rf[ch] = n.ref[ch];
                 nHit += h ? 1 : 0;
             }

@@ -90,7 +90,10 @@ __device__ __forceinline__ void slab4(const float4& q0, const float4& q1, const 
             const float tNear = fmaxf(fmaxf(tnx[e], tny[e]), fmaxf(tnz[e], 0.0f));
             const float tFar = fminf(fminf(tfx[e], tfy[e]), fminf(tfz[e], bound));
             tn[2 * p + e] = tNear;
-            h[2 * p + e] = !(tFar < tNear) && (tFar > 0.0f) && (tNear < r.tmax);
+            // tNear >= 0 and tFar <= bound <= tmax, neither can be NaN (0 and bound are operands), so this
+            // differs from the full interval test only for a box that ends exactly at the origin or begins
+            // exactly at tmax: visiting those is harmless, no primitive test can accept there
+            h[2 * p + e] = !(tFar < tNear);
         }
     }
 #undef YART_PAIR
