@@ -36,6 +36,7 @@ constexpr int kBlock = 256;
 constexpr int kLdsStack = 16;
 constexpr int kOvfStack = kWideStack - kLdsStack;
 constexpr uint32_t kIdle = kWideNone;
+constexpr uint32_t kNeedPop = 0xFFFFFFFEu;       // "take the next stack entry": not a possible leaf reference (first + count <= 2^27 - 1)
 
 __device__ __forceinline__ uint32_t rangeBegin(uint32_t n, uint32_t i, uint32_t kChunk)
 {
@@ -148,7 +149,9 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
     auto pop = [&]() -> uint32_t {
         if (sp == 0) return kIdle;
         --sp;
-        return (sp < kLdsStack) ? ldsStack[sp * kBlock + tid] : ovf[sp - kLdsStack];
+        if (__builtin_expect(sp < kLdsStack, 1)) return ldsStack[sp * kBlock + tid];
+        asm volatile("; deep stack entry" ::: "memory");      // keeps the two paths apart: a ds_read here, a scratch
+        return ovf[sp - kLdsStack];                           // load there, instead of one flat load for both
     };
 
     auto startRay = [&](uint32_t slot) {
@@ -212,7 +215,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
         // leaf is tested in the next leaf phase.  Nodes visited meanwhile are tested against a bound
         // that does not yet know that leaf's hit -- a little extra work for lanes that stay busy.
         for (;;) {
-            if (pend == kIdle && cur != kIdle && (cur & kWideLeafBit)) { pend = cur; cur = pop(); }
+            if (pend == kIdle && cur != kIdle && cur != kNeedPop && (cur & kWideLeafBit)) { pend = cur; cur = kNeedPop; }
+            if (cur == kNeedPop) cur = pop();
             const uint64_t inner = __ballot((cur & kWideLeafBit) == 0);
             if (inner == 0) break;
             if (__popcll(inner) < nodeMin && __ballot(pend != kIdle) != 0) break;
@@ -239,7 +243,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
                     if (tn[3] < inf) push(rf[3]);
                     if (tn[2] < inf) push(rf[2]);
                     if (tn[1] < inf) push(rf[1]);
-                    cur = (tn[0] < inf) ? rf[0] : pop();
+                    cur = (tn[0] < inf) ? rf[0] : kNeedPop;
                 }
             }
         }
