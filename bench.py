@@ -213,9 +213,9 @@ def main():
     copy_gbs = 5 * 2 * src.numel() * 4 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
     del src, dst
     out["roofline"]["stream_copy_GBps"] = round(copy_gbs, 1)
-    out["roofline"]["note"] = ("achieved = algorithmic bytes / kernel time and counts every fetch, cached or not; HBM-side "
-                               "traffic is the smaller `traffic`; the kernel is VALU-bound with ~50% of lanes active "
-                               "(DESIGN.md 3.1)")
+    out["roofline"]["note"] = ("achieved = algorithmic bytes / kernel time and counts every fetch, cached or not (so frac can "
+                               "exceed 1); HBM-side traffic is the smaller `traffic`; the kernel is bound by instruction issue "
+                               "with ~50% of lanes active (DESIGN.md 3.1)")
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(traffic_file):
         try:
