@@ -60,6 +60,8 @@ struct BNode {                          // trivially constructible: the pool bel
     // gets, 0 = the subtree becomes one wide node of its own; take[0] = the split when it does
     float cost[4];
     uint8_t take[4];
+    uint32_t parent;                    // set by the parent when it allocates the pair
+    uint32_t ready;                     // children whose plans are complete (atomic)
 };
 
 struct BNodePool {                      // 2N+2 nodes of address space; only the pages a build touches are committed
@@ -88,45 +90,55 @@ public:
         nodes_.used = next_;
     }
 
+    BNodePool& nodes() { return nodes_; }
+
+private:
     // Which binary nodes become wide nodes.  Opening the child of largest area until four slots are
     // full (the usual greedy collapse) leaves 36 % of the nodes of a single-primitive-leaf tree with
     // two children; the cost of a traversal step does not depend on how many slots are used, so
     // the plan minimises the summed area (= expected visits) of the wide nodes instead: a dynamic
-    // programme over (node, slots available), bottom-up.  Children are always allocated after their
-    // parent, so descending index order is a valid bottom-up order.
-    void planCollapse()
+    // programme over (node, slots available), bottom-up, done while the tree is built.  The plan of a
+    // node needs its children's: a leaf plans itself when it is made and reports to its parent; the
+    // second child to report plans the parent and climbs on, whichever thread that is.
+    void planned(uint32_t idx)
     {
-        for (size_t idx = nodes_.used; idx-- > 0;) {
-            BNode& n = nodes_[idx];
-            if (n.count > 0) {
-                for (int i = 0; i < 4; ++i) { n.cost[i] = 0.0f; n.take[i] = 0; }
-                continue;
-            }
-            const BNode& l = nodes_[n.left];
-            const BNode& r = nodes_[n.right];
-            float forest[5];
-            uint8_t split[5];
-            for (int k = 2; k <= 4; ++k) {
-                forest[k] = std::numeric_limits<float>::infinity();
-                split[k] = 1;
-                for (int j = 1; j < k; ++j) {
-                    const float c = l.cost[j - 1] + r.cost[k - j - 1];
-                    if (c < forest[k]) { forest[k] = c; split[k] = static_cast<uint8_t>(j); }
-                }
-            }
-            const float asNode = n.box.halfArea() + forest[4];
-            n.cost[0] = asNode;
-            n.take[0] = split[4];
-            for (int k = 2; k <= 4; ++k) {
-                if (forest[k] < asNode) { n.cost[k - 1] = forest[k]; n.take[k - 1] = split[k]; }
-                else { n.cost[k - 1] = asNode; n.take[k - 1] = 0; }
-            }
+        for (;;) {
+            planNode(idx);
+            if (idx == 0) return;
+            const uint32_t p = nodes_[idx].parent;
+            if (__atomic_fetch_add(&nodes_[p].ready, 1u, __ATOMIC_ACQ_REL) == 0u) return;     // the sibling is still being built
+            idx = p;
         }
     }
 
-    BNodePool& nodes() { return nodes_; }
+    void planNode(uint32_t idx)
+    {
+        BNode& n = nodes_[idx];
+        if (n.count > 0) {
+            for (int i = 0; i < 4; ++i) { n.cost[i] = 0.0f; n.take[i] = 0; }
+            return;
+        }
+        const BNode& l = nodes_[n.left];
+        const BNode& r = nodes_[n.right];
+        float forest[5];
+        uint8_t split[5];
+        for (int k = 2; k <= 4; ++k) {
+            forest[k] = std::numeric_limits<float>::infinity();
+            split[k] = 1;
+            for (int j = 1; j < k; ++j) {
+                const float c = l.cost[j - 1] + r.cost[k - j - 1];
+                if (c < forest[k]) { forest[k] = c; split[k] = static_cast<uint8_t>(j); }
+            }
+        }
+        const float asNode = n.box.halfArea() + forest[4];
+        n.cost[0] = asNode;
+        n.take[0] = split[4];
+        for (int k = 2; k <= 4; ++k) {
+            if (forest[k] < asNode) { n.cost[k - 1] = forest[k]; n.take[k - 1] = split[k]; }
+            else { n.cost[k - 1] = asNode; n.take[k - 1] = 0; }
+        }
+    }
 
-private:
     struct Job { uint32_t node, begin, end; };
 
     void build(uint32_t node, uint32_t begin, uint32_t end, bool maySpawn)
@@ -151,6 +163,7 @@ private:
             if (m == first || m == last) {
                 n.begin = begin;
                 n.count = count;
+                planned(node);
                 return;
             }
             mid = static_cast<uint32_t>(m - prims_.begin());
@@ -160,6 +173,8 @@ private:
         const uint32_t l = next_.fetch_add(2);
         n.left = l;
         n.right = l + 1;
+        n.ready = 0;
+        nodes_[l].parent = nodes_[l + 1].parent = node;
         if (maySpawn && count > kSpawnAbove) {
             pool_.spawn(Job{ l, begin, mid });
             pool_.spawn(Job{ l + 1, mid, end });
@@ -564,7 +579,6 @@ int buildWideBvh(const float* verts, size_t nVerts, const int32_t* tris, size_t 
         if (!prims.empty()) b.run();
         const char* greedy = std::getenv("YART_WIDE_GREEDY_COLLAPSE");
         const bool plan = !(greedy && greedy[0] == '1');
-        if (plan && !prims.empty()) b.planCollapse();
         const double t1 = now();
         Emitter e(b.nodes(), prims, tri, spheres, out);
         e.planned_ = plan;
