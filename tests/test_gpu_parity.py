@@ -7,6 +7,8 @@ Bars (BASELINE.json north_star / SURVEY.md 8d):
                             |t - t_ref| <= 1e-5 |t_ref|
   * any-hit              -> identical booleans
 """
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -274,3 +276,12 @@ def test_sort_threshold_is_a_pure_performance_policy(monkeypatch):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
     forced.close()
     default.close()
+
+
+def test_oversized_batch_is_refused(accel):
+    """More than 2^31 - 1 rays per call is an error status, checked before any pointer is used."""
+    L = api.lib()
+    small = torch.zeros((4, 8), dtype=torch.float32, device="cuda")
+    out = torch.zeros((4, 4), dtype=torch.float32, device="cuda")
+    st = L.yart_intersect_closest_dev(accel._h, ctypes.c_void_p(small.data_ptr()), 1 << 31, ctypes.c_void_p(out.data_ptr()), 0, None)
+    assert st == 1 and b"2^31" in L.yart_last_error()

@@ -80,3 +80,20 @@ def test_no_gpu_means_loud_failure():
     v, t, s = scenes.random_soup(16)
     with pytest.raises(api.YartError):
         api.Accel(v, t, s)
+
+
+def test_size_limits_are_errors_not_crashes():
+    """Counts beyond what the records can address are refused before any array is touched: 2^29 leaf
+    slots of the reference layout, 2^30 primitives of one kind for the 4-wide tree."""
+    L = api.lib()
+    v = np.zeros((3, 3), np.float32)
+    t = np.zeros((1, 5), np.int32)
+    n = ctypes.c_size_t(0)
+    vp = ctypes.c_void_p
+    assert L.yart_build_host(v.ctypes.data_as(vp), 3, t.ctypes.data_as(vp), 1 << 31, None, ctypes.byref(n), None) == 1
+    assert b"too many triangles" in L.yart_last_error()
+    nn, npr, depth = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_int(0)
+    sph = np.zeros((1, 4), np.float32)
+    assert L.yart_build_wide_host(None, 0, None, 0, sph.ctypes.data_as(vp), 1 << 30, 1, None, ctypes.byref(nn),
+                                  None, None, ctypes.byref(npr), ctypes.byref(depth)) == 1
+    assert b"2^30" in L.yart_last_error()
