@@ -537,33 +537,37 @@ int buildWideBvh(const float* verts, size_t nVerts, const int32_t* tris, size_t 
         return YART_ERR_INVALID_ARGUMENT;
     }
     std::vector<BPrim> prims(nTris + nSpheres);
-    for (size_t i = 0; i < nTris; ++i) {
-        const int32_t* t = tris + i * 5;
-        BPrim& p = prims[i];
-        const float* v0 = verts + static_cast<size_t>(t[0]) * 3;
-        std::memcpy(p.lo, v0, 12);
-        std::memcpy(p.hi, v0, 12);
-        for (int k = 1; k < 3; ++k) {
-            const float* v = verts + static_cast<size_t>(t[k]) * 3;
-            for (int a = 0; a < 3; ++a) { p.lo[a] = std::min(p.lo[a], v[a]); p.hi[a] = std::max(p.hi[a], v[a]); }
+    parallelChunks(nTris, buildThreads(), size_t(1) << 16, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            const int32_t* t = tris + i * 5;
+            BPrim& p = prims[i];
+            const float* v0 = verts + static_cast<size_t>(t[0]) * 3;
+            std::memcpy(p.lo, v0, 12);
+            std::memcpy(p.hi, v0, 12);
+            for (int k = 1; k < 3; ++k) {
+                const float* v = verts + static_cast<size_t>(t[k]) * 3;
+                for (int a = 0; a < 3; ++a) { p.lo[a] = std::min(p.lo[a], v[a]); p.hi[a] = std::max(p.hi[a], v[a]); }
+            }
+            for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * p.lo[a] + 0.5f * p.hi[a];
+            p.id = static_cast<uint32_t>(i);
         }
-        for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * p.lo[a] + 0.5f * p.hi[a];
-        p.id = static_cast<uint32_t>(i);
-    }
-    for (size_t i = 0; i < nSpheres; ++i) {
-        // extents widened by a relative margin: the fp32 slab test must never reject a ray the
-        // fp64 sphere test (include/sphere.h:63-97) accepts
-        const float* s = spheres + i * 4;
-        const float r = std::fabs(s[3]);
-        BPrim& p = prims[nTris + i];
-        for (int a = 0; a < 3; ++a) {
-            const float margin = 1e-5f * (std::fabs(s[a]) + r) + 1e-30f;
-            p.lo[a] = s[a] - r - margin;
-            p.hi[a] = s[a] + r + margin;
-            p.c[a] = s[a];
+    });
+    parallelChunks(nSpheres, buildThreads(), size_t(1) << 16, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            // extents widened by a relative margin: the fp32 slab test must never reject a ray the
+            // fp64 sphere test (include/sphere.h:63-97) accepts
+            const float* s = spheres + i * 4;
+            const float r = std::fabs(s[3]);
+            BPrim& p = prims[nTris + i];
+            for (int a = 0; a < 3; ++a) {
+                const float margin = 1e-5f * (std::fabs(s[a]) + r) + 1e-30f;
+                p.lo[a] = s[a] - r - margin;
+                p.hi[a] = s[a] + r + margin;
+                p.c[a] = s[a];
+            }
+            p.id = kSphereId | static_cast<uint32_t>(i);
         }
-        p.id = kSphereId | static_cast<uint32_t>(i);
-    }
+    });
     // NaN coordinates would poison the binning arithmetic; such primitives can never be hit
     // (every comparison of their tests fails), so they are left out of the tree.
     prims.erase(std::remove_if(prims.begin(), prims.end(), [](const BPrim& p) {
