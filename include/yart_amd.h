@@ -228,7 +228,8 @@ typedef struct YartSurface {    /* 48 bytes */
 /* Uploads what the gather needs: per triangle (leaf order) its geometric normal and its three vertex
  * normals, per sphere its record.  verts / tris / spheres: the arrays yart_accel_create was given;
  * vertex_normals: 3 floats per vertex, same numbering as verts (TriangleMesh::normals_ of every
- * mesh, concatenated).  +64 bytes of HBM per triangle. */
+ * mesh, concatenated).  +64 bytes of HBM per triangle.  Part of setting the accel up: not to be
+ * called while yart_surface* calls on the same accel are in flight. */
 int yart_accel_set_surface_data(YartAccel* accel, const float* verts, size_t n_verts,
                                 const int32_t* tris, size_t n_tris, const float* vertex_normals,
                                 const float* spheres, size_t n_spheres);
