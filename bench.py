@@ -224,6 +224,9 @@ def main():
             if key in tr:
                 out["roofline"]["traffic"] = tr[key]["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = tr[key].get("source")
+                if t_tri > 0:       # the same kernel time against the bytes that actually crossed to HBM
+                    out["roofline"]["hbm_side_GBps"] = round(tr[key]["hbm_bytes_per_launch"] / t_tri / 1e9, 1)
+                    out["roofline"]["hbm_side_frac"] = round(tr[key]["hbm_bytes_per_launch"] / t_tri / 1e9 / HBM_PEAK_GBS, 4)
         except Exception as exc:     # a malformed side file must not break the bench line
             log("traffic.json ignored: %r" % (exc,))
     out["parity_gate"] = {"idempotent_and_counting_variant_equal": same_as_counted,
