@@ -130,14 +130,21 @@ struct ScopedSpan {
     ScopedSpan(YartAccel* accel, int kind, hipStream_t s) : a(accel), stream(s), on(accel->profile)
     {
         span.kind = kind;
-        if (on) {
-            on = hipEventCreate(&span.start) == hipSuccess && hipEventCreate(&span.stop) == hipSuccess &&
-                 hipEventRecord(span.start, stream) == hipSuccess;
-        }
+        if (!on) return;
+        if (hipEventCreate(&span.start) != hipSuccess) { on = false; return; }
+        if (hipEventCreate(&span.stop) != hipSuccess) { (void)hipEventDestroy(span.start); on = false; return; }
+        if (hipEventRecord(span.start, stream) != hipSuccess) { drop(); on = false; }
     }
     ~ScopedSpan()
     {
-        if (on && hipEventRecord(span.stop, stream) == hipSuccess) a->spans.push_back(span);
+        if (!on) return;
+        if (hipEventRecord(span.stop, stream) == hipSuccess) a->spans.push_back(span);
+        else drop();
+    }
+    void drop()
+    {
+        (void)hipEventDestroy(span.start);
+        (void)hipEventDestroy(span.stop);
     }
 };
 
