@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libyart_amd.so")
+LIB_PATH = os.environ.get("YART_AMD_LIB") or os.path.join(_HERE, "libyart_amd.so")      # override: A/B runs of two builds
 
 YART_DEFAULT = 0
 YART_REFERENCE_RULE = 1 << 0
