@@ -33,7 +33,7 @@ namespace yart {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kLdsStack = 16;
+constexpr int kLdsStack = 19;
 constexpr int kOvfStack = kWideStack - kLdsStack;
 constexpr uint32_t kIdle = kWideNone;
 constexpr uint32_t kNeedPop = 0xFFFFFFFEu;       // "take the next stack entry": not a possible leaf reference (first + count <= 2^27 - 1)
