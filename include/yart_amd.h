@@ -303,7 +303,7 @@ int yart_film_write_bmp(const char* path, const float* rgb, int32_t width, int32
  * kernel, or the triangle-tree pass with YART_REFERENCE_TREE / _RULE) and ms_spheres (the other
  * passes: sphere-tree pass of the reference-tree path, fix-up launches of the default path); yart_accel_profile_read synchronises those events,
  * adds their durations (milliseconds) and launch counts to the outputs and clears
- * the list.  Not thread-safe; diagnostic. */
+ * the list.  Diagnostic; the span list is locked, so calls from several host threads are safe. */
 int yart_accel_profile_enable(YartAccel* accel, int enable);
 int yart_accel_profile_read(YartAccel* accel, double* ms_sort, double* ms_spheres,
                             double* ms_triangles, uint64_t* n_calls);

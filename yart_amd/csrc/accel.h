@@ -1,0 +1,101 @@
+// accel.h -- the accel object behind the opaque YartAccel handle of include/yart_amd.h.
+// Private to the library: shared by the translation units of the C-ABI layer.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/yart_amd.h"
+#include "bvh_build.h"
+
+struct YartAccel {
+    int device = 0;
+    int numCUs = 0;
+    yart::TriangleBvh tri;            // host copies (nodes / triaccel kept for introspection)
+    size_t numTriPairs = 0, numSphPairs = 0, numSpheres = 0;
+    int sphDepth = 0;
+    float sceneLo[3], sceneHi[3];     // bounds of everything, for the sort key grid
+    // device memory
+    void* dTriPairs = nullptr;
+    void* dTriAccel = nullptr;
+    void* dSphPairs = nullptr;
+    void* dSphRecs = nullptr;
+    void* dSphIndex = nullptr;
+    void* dWideNodes = nullptr;       // the engine's own 4-wide triangle+sphere tree (wide_build.h)
+    void* dWideRowsA = nullptr;
+    void* dWideRowsBC = nullptr;
+    void* dSurfRows = nullptr;        // hit post-processing (yart_accel_set_surface_data)
+    void* dSurfSpheres = nullptr;
+    bool hasWide = false;
+    size_t wideNodes = 0, widePrims = 0;   // array sizes; the device copy is the only one kept
+    int wideDepth = 0;
+    size_t deviceBytes = 0;
+    // per-kernel timing (yart_accel_profile_*): kind 0 = sort, 1 = other passes, 2 = main traversal kernel
+    struct Span { hipEvent_t start, stop; int kind; };
+    bool profile = false;
+    std::mutex profileMutex;          // guards spans / profiledCalls: intersect calls come from several host threads
+    std::vector<Span> spans;
+    uint64_t profiledCalls = 0;
+    // scheduling knobs of the persistent kernel (YART_REFILL_MIN / YART_NODE_MIN override)
+    uint32_t refillMin = 16, nodeMin = 24;                    // reference-tree kernels
+    uint32_t wideRefillMin = 16, wideNodeMin = 40, wideChunk = 64, wideBlocksPerCU = 0;   // wide-tree kernel
+    uint32_t sortMinRays = 3u << 19;   // below ~1.5 M rays the sort costs more than it saves (profiles/r01_batch_sweep.jsonl)
+    uint32_t sortOctShift = 0, sortGridBits = 7;      // 7: 24-bit keys = 3 radix passes; finer grids measured no better
+    // Small host-buffer calls (the one-ray-per-call pattern of the reference's renderer,
+    // src/renderer.cpp:59,104): a pool of { stream, pinned host block the kernels read and
+    // write in place } so that such a call costs launches + one stream synchronise, no
+    // allocation and no copy.  A context is taken for the duration of one call.
+    struct Staging { hipStream_t stream = nullptr; void* host = nullptr; void* dev = nullptr;
+                     void* big = nullptr; size_t bigBytes = 0; };     // + a device block kept for larger batches
+    std::mutex stagingMutex;
+    std::vector<Staging> stagingFree;
+
+    // What the launches of ONE stream need beside the caller's arrays: the work-counter slots of the
+    // persistent kernels (4 x 256 bytes, one per launch of a call) and the coherence sort's workspace,
+    // kept and grown on demand.  Launches on a stream run in order, so a stream's calls can share
+    // them; calls on different streams never do.  `submit` is held while a call enqueues its
+    // launches (two host threads feeding one stream would otherwise interleave sort and traversal).
+    struct StreamCtx {
+        std::mutex submit;
+        void* counters = nullptr;
+        void* sortWs = nullptr;
+        size_t sortWsBytes = 0;
+    };
+    std::mutex ctxMutex;
+    std::unordered_map<void*, StreamCtx*> ctx;
+};
+
+namespace yart {
+
+constexpr size_t kCounterBlockBytes = 1024;      // 4 work-counter slots of 256 bytes
+
+// Scratch of one intersect call.  counters: kCounterBlockBytes of device memory.
+struct CallScratch {
+    void* counters = nullptr;
+    void* sortWs = nullptr;
+    size_t sortWsBytes = 0;
+};
+
+struct Launch {
+    bool any, count;
+    const YartRay* rays;
+    size_t n;
+    YartHit* hits;
+    uint8_t* occluded;
+    uint32_t* counts;
+    unsigned flags;
+    hipStream_t stream;
+};
+
+// Enqueues the launches of one intersect call (capi.cpp).  scratch == nullptr: the stream's own
+// context is used and grown as needed (may allocate); otherwise nothing is allocated and a batch
+// the given workspace cannot sort is an error.
+int runIntersect(YartAccel* a, const Launch& L, const CallScratch* scratch);
+
+int failStatus(int status, const std::string& msg);
+
+} // namespace yart

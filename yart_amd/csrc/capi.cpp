@@ -12,10 +12,12 @@
 #include <new>
 #include <memory>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/yart_amd.h"
 #include "bvh_build.h"
+#include "accel.h"
 #include "traverse.h"
 #include "wide_build.h"
 #include "obj_ingest.h"
@@ -42,59 +44,11 @@ int failHip(hipError_t e, const char* what)
     return YART_ERR_HIP;
 }
 
-constexpr int kCounterSlots = 1024;   // 256-byte work-counter slots, handed out round-robin: a slot is reused only after 1023 later launches
-
 } // namespace
 
-struct YartAccel {
-    int device = 0;
-    int numCUs = 0;
-    yart::TriangleBvh tri;            // host copies (nodes / triaccel kept for introspection)
-    size_t numTriPairs = 0, numSphPairs = 0, numSpheres = 0;
-    int sphDepth = 0;
-    float sceneLo[3], sceneHi[3];     // bounds of everything, for the sort key grid
-    // device memory
-    void* dTriPairs = nullptr;
-    void* dTriAccel = nullptr;
-    void* dSphPairs = nullptr;
-    void* dSphRecs = nullptr;
-    void* dSphIndex = nullptr;
-    void* dCounters = nullptr;
-    void* dWideNodes = nullptr;       // the engine's own 4-wide triangle+sphere tree (wide_build.h)
-    void* dWideRowsA = nullptr;
-    void* dWideRowsBC = nullptr;
-    void* dSurfRows = nullptr;        // hit post-processing (yart_accel_set_surface_data)
-    void* dSurfSpheres = nullptr;
-    bool hasWide = false;
-    size_t wideNodes = 0, widePrims = 0;   // array sizes; the device copy is the only one kept
-    int wideDepth = 0;
-    size_t deviceBytes = 0;
-    std::atomic<unsigned> nextCounter{ 0 };
-    // per-kernel timing (yart_accel_profile_*): kind 0 = sort, 1 = sphere tree, 2 = triangle tree
-    struct Span { hipEvent_t start, stop; int kind; };
-    bool profile = false;
-    std::vector<Span> spans;
-    uint64_t profiledCalls = 0;
-    // scheduling knobs of the persistent kernel (YART_REFILL_MIN / YART_NODE_MIN override)
-    uint32_t refillMin = 16, nodeMin = 24;                    // reference-tree kernels
-    uint32_t wideRefillMin = 16, wideNodeMin = 40, wideChunk = 64, wideBlocksPerCU = 0;   // wide-tree kernel
-    uint32_t sortMinRays = 3u << 19;   // below ~1.5 M rays the sort costs more than it saves (profiles/r01_batch_sweep.jsonl)
-    uint32_t sortOctShift = 0, sortGridBits = 7;      // 7: 24-bit keys = 3 radix passes; finer grids measured no better
-    // Small host-buffer calls (the one-ray-per-call pattern of the reference's renderer,
-    // src/renderer.cpp:59,104): a pool of { stream, pinned host block the kernels read and
-    // write in place } so that such a call costs launches + one stream synchronise, no
-    // allocation and no copy.  A context is taken for the duration of one call.
-    struct Staging { hipStream_t stream = nullptr; void* host = nullptr; void* dev = nullptr;
-                     void* big = nullptr; size_t bigBytes = 0; };     // + a device block kept for larger batches
-    std::mutex stagingMutex;
-    std::vector<Staging> stagingFree;
-
-    uint32_t* counterSlot()
-    {
-        const unsigned s = nextCounter.fetch_add(1) % kCounterSlots;
-        return reinterpret_cast<uint32_t*>(static_cast<char*>(dCounters) + 256 * s);
-    }
-};
+namespace yart {
+int failStatus(int status, const std::string& msg) { return fail(status, msg); }
+}
 
 namespace {
 
@@ -138,7 +92,10 @@ struct ScopedSpan {
     ~ScopedSpan()
     {
         if (!on) return;
-        if (hipEventRecord(span.stop, stream) == hipSuccess) a->spans.push_back(span);
+        if (hipEventRecord(span.stop, stream) == hipSuccess) {
+            std::lock_guard<std::mutex> lock(a->profileMutex);
+            a->spans.push_back(span);
+        }
         else drop();
     }
     void drop()
@@ -148,18 +105,26 @@ struct ScopedSpan {
     }
 };
 
-struct Launch {
-    bool any, count;
-    const YartRay* rays;
-    size_t n;
-    YartHit* hits;
-    uint8_t* occluded;
-    uint32_t* counts;
-    unsigned flags;
-    hipStream_t stream;
-};
+// The calling stream's context (work-counter slots + sort workspace), created at the stream's
+// first call.  Contexts live as long as the accel.
+YartAccel::StreamCtx* streamContext(YartAccel* a, hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lock(a->ctxMutex);
+    auto it = a->ctx.find(static_cast<void*>(stream));
+    if (it != a->ctx.end()) return it->second;
+    auto c = std::make_unique<YartAccel::StreamCtx>();
+    hipError_t e = hipMalloc(&c->counters, yart::kCounterBlockBytes);
+    if (e != hipSuccess) { fail(YART_ERR_OUT_OF_MEMORY, std::string("hipMalloc(work counters): ") + hipGetErrorString(e)); return nullptr; }
+    YartAccel::StreamCtx* raw = c.release();
+    a->ctx.emplace(static_cast<void*>(stream), raw);
+    return raw;
+}
 
-int run(YartAccel* a, const Launch& L)
+} // namespace
+
+namespace yart {
+
+int runIntersect(YartAccel* a, const Launch& L, const CallScratch* given)
 {
     if (!a) return fail(YART_ERR_INVALID_ARGUMENT, "null accel");
     if (L.n == 0) return YART_OK;
@@ -174,21 +139,48 @@ int run(YartAccel* a, const Launch& L)
     const bool prune = !(L.flags & YART_REFERENCE_RULE);
     const bool persistent = !(L.flags & YART_STATIC_LAUNCH);
     const uint32_t n = static_cast<uint32_t>(L.n);
+    const bool sorted = (L.flags & YART_SORT_RAYS) && n >= a->sortMinRays;
 
-    uint32_t* perm = nullptr;
-    void* sortWs = nullptr;
-    if ((L.flags & YART_SORT_RAYS) && n >= a->sortMinRays) {
-        const size_t wsBytes = yart::sortWorkspaceBytes(n);
-        const size_t permBytes = (static_cast<size_t>(n) * 4 + 255) & ~size_t(255);
-        hipError_t e = hipMallocAsync(&sortWs, wsBytes + permBytes, L.stream);
-        if (e != hipSuccess) return fail(YART_ERR_OUT_OF_MEMORY, std::string("hipMallocAsync: ") + hipGetErrorString(e));
-        perm = reinterpret_cast<uint32_t*>(static_cast<char*>(sortWs) + wsBytes);
+    // scratch of this call: the caller's (nothing is allocated) or the stream's own context
+    CallScratch sc;
+    std::unique_lock<std::mutex> submit;
+    if (given) {
+        sc = *given;
+        if (sorted && yart::sortWorkspaceBytes(n) > sc.sortWsBytes)
+            return fail(YART_ERR_INVALID_ARGUMENT, "batch too large for the given sort workspace");
+    } else {
+        YartAccel::StreamCtx* c = streamContext(a, L.stream);
+        if (!c) return YART_ERR_OUT_OF_MEMORY;
+        submit = std::unique_lock<std::mutex>(c->submit);
+        if (sorted) {
+            const size_t need = yart::sortWorkspaceBytes(n);
+            if (need > c->sortWsBytes) {
+                (void)hipFree(c->sortWs);          // synchronises: no earlier launch still reads it
+                c->sortWs = nullptr;
+                c->sortWsBytes = 0;
+                const hipError_t e = hipMalloc(&c->sortWs, need);
+                if (e != hipSuccess) return fail(YART_ERR_OUT_OF_MEMORY, std::string("hipMalloc(sort workspace): ") + hipGetErrorString(e));
+                c->sortWsBytes = need;
+            }
+        }
+        sc.counters = c->counters;
+        sc.sortWs = c->sortWs;
+        sc.sortWsBytes = c->sortWsBytes;
+    }
+    // one 256-byte slot per launch of this call; each launcher zeroes its own on the stream
+    uint32_t* const slot0 = static_cast<uint32_t*>(sc.counters);
+    uint32_t* const slot1 = slot0 + 64;
+    uint32_t* const slot2 = slot0 + 128;
+
+    const uint32_t* perm = nullptr;
+    if (sorted) {
+        hipError_t e;
         {
             ScopedSpan span(a, 0, L.stream);
-            e = yart::sortRays(reinterpret_cast<const float4*>(L.rays), n, a->sceneLo, a->sceneHi, a->sortOctShift, a->sortGridBits, perm,
-                               sortWs, wsBytes, L.stream);
+            e = yart::sortRays(reinterpret_cast<const float4*>(L.rays), n, a->sceneLo, a->sceneHi, a->sortOctShift, a->sortGridBits,
+                               &perm, sc.sortWs, sc.sortWsBytes, L.stream);
         }
-        if (e != hipSuccess) { (void)hipFreeAsync(sortWs, L.stream); return failHip(e, "sortRays"); }
+        if (e != hipSuccess) return failHip(e, "sortRays");
     }
 
     yart::TraceParams P;
@@ -214,7 +206,7 @@ int run(YartAccel* a, const Launch& L)
         W.rowsBC = static_cast<const float4*>(a->dWideRowsBC);
         W.rays = P.rays; W.perm = perm; W.n = n;
         W.hits = P.hits; W.occluded = P.occluded; W.counts = P.counts;
-        W.workCounter = a->counterSlot();
+        W.workCounter = slot0;
         W.deferFlag = W.workCounter + 1;
         W.refillMin = a->wideRefillMin; W.nodeMin = a->wideNodeMin; W.chunk = a->wideChunk; W.maxBlocksPerCU = a->wideBlocksPerCU;
         {
@@ -233,7 +225,7 @@ int run(YartAccel* a, const Launch& L)
         P.pairs = static_cast<const float4*>(a->dSphPairs);
         P.prims = static_cast<const float4*>(a->dSphRecs);
         P.primIndex = static_cast<const uint32_t*>(a->dSphIndex);
-        P.workCounter = a->counterSlot();
+        P.workCounter = slot1;
         P.chained = 0;
         ScopedSpan span(a, 1, L.stream);
         e = yart::launchTrace(P, 1, L.any, prune, L.count, persistent, a->numCUs, L.stream);
@@ -242,16 +234,26 @@ int run(YartAccel* a, const Launch& L)
         P.pairs = static_cast<const float4*>(a->dTriPairs);
         P.prims = static_cast<const float4*>(a->dTriAccel);
         P.primIndex = nullptr;
-        P.workCounter = a->counterSlot();
+        P.workCounter = slot2;
         P.chained = a->numSpheres > 0 ? 1u : 0u;
         ScopedSpan span(a, fixupOnly ? 1 : 2, L.stream);
         e = yart::launchTrace(P, 0, L.any, prune, L.count, persistent, a->numCUs, L.stream);
     }
-    if (sortWs) (void)hipFreeAsync(sortWs, L.stream);
-    if (a->profile) a->profiledCalls++;
+    if (a->profile) {
+        std::lock_guard<std::mutex> lock(a->profileMutex);
+        a->profiledCalls++;
+    }
     if (e != hipSuccess) return failHip(e, "traversal launch");
     return YART_OK;
 }
+
+} // namespace yart
+
+namespace {
+
+using yart::Launch;
+
+int run(YartAccel* a, const Launch& L) { return yart::runIntersect(a, L, nullptr); }
 
 } // namespace
 
@@ -340,12 +342,6 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
         a->widePrims = wide.rowsA.size() / 4;
         a->wideDepth = wide.depth;
     }
-    if (st == YART_OK) {
-        hipError_t e = hipMalloc(&a->dCounters, 256 * kCounterSlots);
-        if (e != hipSuccess) st = fail(YART_ERR_OUT_OF_MEMORY, "hipMalloc(counters) failed");
-        else if ((e = hipMemset(a->dCounters, 0, 256 * kCounterSlots)) != hipSuccess) st = failHip(e, "hipMemset");
-        else a->deviceBytes += 256 * kCounterSlots;
-    }
     if (st != YART_OK) { yart_accel_destroy(a); return st; }
     // the device copy is authoritative from here on; the pair array is not needed on the host
     a->tri.pairs.clear();
@@ -364,7 +360,11 @@ void yart_accel_destroy(YartAccel* a)
         (void)hipFree(a->dSphPairs);
         (void)hipFree(a->dSphRecs);
         (void)hipFree(a->dSphIndex);
-        (void)hipFree(a->dCounters);
+        for (auto& kv : a->ctx) {
+            (void)hipFree(kv.second->counters);
+            (void)hipFree(kv.second->sortWs);
+            delete kv.second;
+        }
         (void)hipFree(a->dWideNodes);
         (void)hipFree(a->dWideRowsA);
         (void)hipFree(a->dWideRowsBC);
@@ -583,7 +583,15 @@ int yart_accel_profile_read(YartAccel* a, double* ms_sort, double* ms_spheres, d
     DeviceGuard guard(a->device);
     double ms[3] = { 0.0, 0.0, 0.0 };
     int st = YART_OK;
-    for (auto& s : a->spans) {
+    std::vector<YartAccel::Span> spans;
+    uint64_t calls = 0;
+    {
+        std::lock_guard<std::mutex> lock(a->profileMutex);
+        spans.swap(a->spans);
+        calls = a->profiledCalls;
+        a->profiledCalls = 0;
+    }
+    for (auto& s : spans) {
         float t = 0.0f;
         hipError_t e = hipEventSynchronize(s.stop);
         if (e == hipSuccess) e = hipEventElapsedTime(&t, s.start, s.stop);
@@ -592,12 +600,10 @@ int yart_accel_profile_read(YartAccel* a, double* ms_sort, double* ms_spheres, d
         (void)hipEventDestroy(s.start);
         (void)hipEventDestroy(s.stop);
     }
-    a->spans.clear();
     if (ms_sort) *ms_sort = ms[0];
     if (ms_spheres) *ms_spheres = ms[1];
     if (ms_triangles) *ms_triangles = ms[2];
-    if (n_calls) *n_calls = a->profiledCalls;
-    a->profiledCalls = 0;
+    if (n_calls) *n_calls = calls;
     return st;
 }
 

@@ -51,29 +51,32 @@ size_t alignUp(size_t v) { return (v + 255) & ~size_t(255); }
 size_t cubTempBytes(uint32_t n)
 {
     size_t bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                       (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, 30, 0);
+    hipcub::DoubleBuffer<uint32_t> k(nullptr, nullptr), v(nullptr, nullptr);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k, v, (int)n, 0, 30, 0);
     return bytes;
 }
 
 } // namespace
 
+// Workspace: keys and ray numbers, two buffers each (the radix passes ping-pong between them, so the
+// library needs no copies of its own), then hipcub's histograms.
 size_t sortWorkspaceBytes(uint32_t n)
 {
-    return 3 * alignUp((size_t)n * 4) + alignUp(cubTempBytes(n));
+    return 4 * alignUp((size_t)n * 4) + alignUp(cubTempBytes(n));
 }
 
 hipError_t sortRays(const float4* rays, uint32_t n, const float lo[3], const float hi[3], uint32_t octShift,
-                    uint32_t gridBits, uint32_t* perm, void* workspace, size_t workspaceBytes, hipStream_t stream)
+                    uint32_t gridBits, const uint32_t** perm, void* workspace, size_t workspaceBytes, hipStream_t stream)
 {
+    *perm = nullptr;
     if (n == 0) return hipSuccess;
     const size_t seg = alignUp((size_t)n * 4);
+    if (workspaceBytes < 4 * seg) return hipErrorInvalidValue;
     char* w = static_cast<char*>(workspace);
-    uint32_t* keysIn = reinterpret_cast<uint32_t*>(w);
-    uint32_t* keysOut = reinterpret_cast<uint32_t*>(w + seg);
-    uint32_t* idsIn = reinterpret_cast<uint32_t*>(w + 2 * seg);
-    void* temp = w + 3 * seg;
-    size_t tempBytes = workspaceBytes - 3 * seg;
+    hipcub::DoubleBuffer<uint32_t> keys(reinterpret_cast<uint32_t*>(w), reinterpret_cast<uint32_t*>(w + seg));
+    hipcub::DoubleBuffer<uint32_t> ids(reinterpret_cast<uint32_t*>(w + 2 * seg), reinterpret_cast<uint32_t*>(w + 3 * seg));
+    void* temp = w + 4 * seg;
+    size_t tempBytes = workspaceBytes - 4 * seg;
     if (gridBits < 1) gridBits = 1;
     if (gridBits > 9) gridBits = 9;
     const float cells = static_cast<float>(1u << gridBits);
@@ -85,10 +88,12 @@ hipError_t sortRays(const float4* rays, uint32_t n, const float lo[3], const flo
         s[a] = (ext > 0.0f && ext < 3.0e38f) ? cells / ext : 0.0f;
     }
     hipLaunchKernelGGL(rayKeys, dim3((n + 255) / 256), dim3(256), 0, stream, rays, n,
-                       lo[0], lo[1], lo[2], s[0], s[1], s[2], octShift, cells - 1.0f, keysIn, idsIn);
+                       lo[0], lo[1], lo[2], s[0], s[1], s[2], octShift, cells - 1.0f, keys.Current(), ids.Current());
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, keysIn, keysOut, idsIn, perm, (int)n, 0, keyBits, stream);
+    e = hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, keys, ids, (int)n, 0, keyBits, stream);
+    *perm = ids.Current();           // whichever buffer the last pass wrote (known on the host: it depends on the pass count)
+    return e;
 }
 
 } // namespace yart

@@ -66,11 +66,11 @@ hipError_t launchTraceWide(const WideParams& P, bool any, bool count, bool persi
 hipError_t launchTrace(const TraceParams& P, int prim, bool any, bool prune, bool count,
                        bool persistent, int numCUs, hipStream_t stream);
 
-// Ray sorting (sort.hip): fills perm[0..n) with ray numbers ordered by a Morton key of
-// the ray origin inside [lo,hi] plus the direction octant.  `keys` and `tmp` are
-// n-element scratch arrays.
+// Ray sorting (sort.hip): (*perm)[0..n) = ray numbers ordered by a Morton key of
+// the ray origin inside [lo,hi] plus the direction octant.  *perm points into `workspace`
+// (sortWorkspaceBytes(n) bytes), valid until the workspace is reused.
 hipError_t sortRays(const float4* rays, uint32_t n, const float lo[3], const float hi[3], uint32_t octShift,
-                    uint32_t gridBits, uint32_t* perm, void* workspace, size_t workspaceBytes, hipStream_t stream);
+                    uint32_t gridBits, const uint32_t** perm, void* workspace, size_t workspaceBytes, hipStream_t stream);
 size_t sortWorkspaceBytes(uint32_t n);
 
 // Hit post-processing (surface.hip): rows = 64 B per triangle in leaf-slot order (geometric normal, the three
