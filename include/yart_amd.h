@@ -159,6 +159,21 @@ int yart_intersect_any_counted_dev(YartAccel* accel, const YartRay* d_rays, size
                                    uint8_t* d_occluded, uint32_t* d_counts,
                                    unsigned flags, void* stream);
 
+/* ---- intersection without allocation ---------------------------------- */
+
+/* No counterpart in the reference.  For callers that cannot allocate: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  Same contract, kernels and results as
+ * yart_intersect_closest_dev, but the scratch those kernels need beyond the caller's arrays (the
+ * persistent kernels' work counters, the coherence sort's keys / permutation / histograms) lives in
+ * one static 40 MiB device array per GPU instead of per-stream blocks grown with hipMalloc, so the
+ * call reaches no hipMalloc / hipFree / allocating library routine.  Limits: n <=
+ * YART_NOALLOC_MAX_RAYS (larger batches return YART_ERR_INVALID_ARGUMENT); every call on one GPU
+ * shares that GPU's array, so calls that OVERLAP on one GPU (other streams or threads, any accel)
+ * race -- issue them on one stream or order them with events. */
+#define YART_NOALLOC_MAX_RAYS 2097152u
+int yart_intersect_closest_noalloc_dev(YartAccel* accel, const YartRay* d_rays, size_t n,
+                                       YartHit* d_hits, unsigned flags, void* stream);
+
 /* ---- intersection: host buffers (copies in, runs, copies out, syncs) --- */
 
 /* Same contracts as the _dev calls; the batch-of-one form of these is what the

@@ -18,6 +18,7 @@ YART_STATIC_LAUNCH = 1 << 1
 YART_SORT_RAYS = 1 << 2
 YART_REFERENCE_TREE = 1 << 3
 YART_RAYS_REGULAR = 1 << 4
+YART_NOALLOC_MAX_RAYS = 2097152
 
 NODE_DTYPE = np.dtype([("bounds", np.float32, 6), ("offset", np.uint32),
                        ("numTriangles", np.uint8), ("splitAxis", np.uint8),
@@ -29,7 +30,7 @@ HIT_DTYPE = np.dtype([("t", np.float32), ("u", np.float32), ("v", np.float32), (
 
 EXPORTS = [
     "yart_accel_create", "yart_accel_destroy",
-    "yart_intersect_closest_dev", "yart_intersect_any_dev",
+    "yart_intersect_closest_dev", "yart_intersect_any_dev", "yart_intersect_closest_noalloc_dev",
     "yart_intersect_closest_counted_dev", "yart_intersect_any_counted_dev",
     "yart_intersect_closest", "yart_intersect_any",
     "yart_accel_num_nodes", "yart_accel_num_triangles", "yart_accel_num_spheres",
@@ -81,7 +82,7 @@ def lib():
     L.yart_accel_create.argtypes = [_vp, _sz, _vp, _sz, _vp, _sz, ctypes.c_int, ctypes.POINTER(_vp)]
     L.yart_accel_destroy.argtypes = [_vp]
     L.yart_accel_destroy.restype = None
-    for name in ("yart_intersect_closest_dev", "yart_intersect_any_dev"):
+    for name in ("yart_intersect_closest_dev", "yart_intersect_any_dev", "yart_intersect_closest_noalloc_dev"):
         getattr(L, name).argtypes = [_vp, _vp, _sz, _vp, ctypes.c_uint, _vp]
     for name in ("yart_intersect_closest_counted_dev", "yart_intersect_any_counted_dev"):
         getattr(L, name).argtypes = [_vp, _vp, _sz, _vp, _vp, ctypes.c_uint, _vp]
@@ -307,11 +308,18 @@ class Accel:
             raise YartError("rays live on another device than the accel")
         return rays
 
-    def intersect_closest(self, rays, flags=0, out=None, counts=None, stream=None):
-        """rays [n,8] float32 -> hits [n,4] float32 (t,u,v,prim-as-int32-bits)."""
+    def intersect_closest(self, rays, flags=0, out=None, counts=None, stream=None, noalloc=False):
+        """rays [n,8] float32 -> hits [n,4] float32 (t,u,v,prim-as-int32-bits).
+        noalloc: through yart_intersect_closest_noalloc_dev (`out` must be given)."""
         import torch
         rays = self._rays(rays)
         n = rays.shape[0]
+        if noalloc:
+            if out is None or counts is not None:
+                raise YartError("noalloc: pass `out`, no `counts`")
+            _check(lib().yart_intersect_closest_noalloc_dev(self._h, _vp(rays.data_ptr()), n, _vp(out.data_ptr()),
+                                                            flags, self._stream(stream)))
+            return out
         if out is None:
             out = torch.empty((n, 4), dtype=torch.float32, device=rays.device)
         if counts is not None:

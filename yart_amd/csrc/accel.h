@@ -1,5 +1,6 @@
 // accel.h -- the accel object behind the opaque YartAccel handle of include/yart_amd.h.
-// Private to the library: shared by the translation units of the C-ABI layer.
+// Private to the library: shared by the C-ABI layer (capi.cpp) and the entry point that allocates
+// nothing (noalloc.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -67,6 +68,10 @@ struct YartAccel {
     };
     std::mutex ctxMutex;
     std::unordered_map<void*, StreamCtx*> ctx;
+
+    // the static scratch of the entry point that allocates nothing (noalloc.hip), on this accel's device
+    void* noallocScratch = nullptr;
+    size_t noallocBytes = 0;
 };
 
 namespace yart {
@@ -95,6 +100,9 @@ struct Launch {
 // context is used and grown as needed (may allocate); otherwise nothing is allocated and a batch
 // the given workspace cannot sort is an error.
 int runIntersect(YartAccel* a, const Launch& L, const CallScratch* scratch);
+
+// noalloc.hip: address and size of this device's copy of the static scratch array (device current).
+int noallocScratchOfDevice(int device, void** ptr, size_t* bytes);
 
 int failStatus(int status, const std::string& msg);
 

@@ -342,6 +342,9 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
         a->widePrims = wide.rowsA.size() / 4;
         a->wideDepth = wide.depth;
     }
+    // this device's copy of the static scratch of yart_intersect_closest_noalloc_dev (looked up once per
+    // device, with that device current)
+    if (st == YART_OK) st = yart::noallocScratchOfDevice(device, &a->noallocScratch, &a->noallocBytes);
     if (st != YART_OK) { yart_accel_destroy(a); return st; }
     // the device copy is authoritative from here on; the pair array is not needed on the host
     a->tri.pairs.clear();
