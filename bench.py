@@ -177,19 +177,40 @@ def main():
     t_tri = prof["ms_triangles"] / max(1, args.steps) * 1e-3
     t_sph = prof["ms_spheres"] / max(1, args.steps) * 1e-3
     t_sort = prof["ms_sort"] / max(1, args.steps) * 1e-3
-    achieved = bytes_tri / t_tri / 1e9 if t_tri > 0 else 0.0
+    # Roofline of the dominant kernel, HBM side: bytes that crossed between L2 and memory per launch
+    # (rocprofv3 PMC passes of this same command, profiles/traffic.json: FETCH_SIZE with the factor
+    # calibrated on this kernel's access shape by tools/calib_fetch.hip + WRITE_SIZE) / this run's
+    # kernel time (HIP events on the launch stream).  The cache-inclusive algorithmic rate (every
+    # fetch the traversal issues, whether a cache served it or not) is reported beside it; it is not
+    # a fraction of anything and can exceed the HBM peak.
+    algorithmic = bytes_tri / t_tri / 1e9 if t_tri > 0 else 0.0
+    traffic = None
+    traffic_source = None
+    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+    key = "%stris=%d,spheres=%d,rays=%d,s=%g" % ("" if wide else "reftree,", args.tris, args.spheres, args.rays, args.s)
+    if os.path.exists(traffic_file):
+        try:
+            tr = json.load(open(traffic_file))
+            if key in tr:
+                traffic = tr[key]["hbm_bytes_per_launch"]
+                traffic_source = tr[key].get("source")
+        except Exception as exc:     # a malformed side file must not break the bench line
+            log("traffic.json ignored: %r" % (exc,))
+    achieved = traffic / t_tri / 1e9 if (traffic and t_tri > 0) else None
     out["roofline"] = {
         "bound": "hbm",
         "kernel": ("traceWide<closest> (yart_amd/csrc/traverse_wide.hip)" if wide
                    else "traceKernel<triangles, closest, pruned> (yart_amd/csrc/traverse.hip)"),
-        "achieved": round(achieved, 1),
+        "achieved": round(achieved, 1) if achieved is not None else None,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4),
-        "traffic": None,
+        "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved is not None else None,
+        "traffic": traffic,
+        "traffic_source": traffic_source,
+        "kernel_ms": round(t_tri * 1e3, 3),
+        "algorithmic_GBps": round(algorithmic, 1),
         "algorithmic_bytes_per_launch": int(bytes_tri),
         "algorithmic_bytes_per_ray": round(bytes_tri / args.rays, 1),
-        "kernel_ms": round(t_tri * 1e3, 3),
         "per_ray_fetches": ({"child_records_16B": round(float(mean_counts[0]), 2),
                              "triangle_plane_rows_16B": round(float(mean_counts[1]), 2),
                              "second_stage_rows_32B": round(float(mean_counts[2]), 2),
@@ -213,22 +234,13 @@ def main():
     copy_gbs = 5 * 2 * src.numel() * 4 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
     del src, dst
     out["roofline"]["stream_copy_GBps"] = round(copy_gbs, 1)
-    out["roofline"]["note"] = ("achieved = algorithmic bytes / kernel time and counts every fetch, cached or not (so frac can "
-                               "exceed 1); HBM-side traffic is the smaller `traffic`; the kernel is bound by instruction issue "
-                               "with ~50% of lanes active (DESIGN.md 3.1)")
-    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(traffic_file):
-        try:
-            tr = json.load(open(traffic_file))
-            key = "%stris=%d,spheres=%d,rays=%d,s=%g" % ("" if wide else "reftree,", args.tris, args.spheres, args.rays, args.s)
-            if key in tr:
-                out["roofline"]["traffic"] = tr[key]["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = tr[key].get("source")
-                if t_tri > 0:       # the same kernel time against the bytes that actually crossed to HBM
-                    out["roofline"]["hbm_side_GBps"] = round(tr[key]["hbm_bytes_per_launch"] / t_tri / 1e9, 1)
-                    out["roofline"]["hbm_side_frac"] = round(tr[key]["hbm_bytes_per_launch"] / t_tri / 1e9 / HBM_PEAK_GBS, 4)
-        except Exception as exc:     # a malformed side file must not break the bench line
-            log("traffic.json ignored: %r" % (exc,))
+    out["roofline"]["note"] = ("achieved = HBM-side bytes per launch (PMC, separate passes of this command; see traffic_source) / "
+                               "this run's kernel time; frac = achieved / 8 TB/s.  algorithmic_GBps counts every fetch the traversal "
+                               "issues, cached or not: 70% of them are served by L2, so it is not a roofline fraction.  The kernel is "
+                               "bound by instruction issue and per-lane L1 requests, not by bytes (DESIGN.md 3.1)"
+                               if achieved is not None else
+                               "no PMC traffic figure for this configuration in profiles/traffic.json: HBM-side rate not available; "
+                               "algorithmic_GBps counts every fetch, cached or not")
     out["parity_gate"] = {"idempotent_and_counting_variant_equal": same_as_counted,
                           "sorted_persistent_equals_unsorted_static": order_independent,
                           "any_hit_consistent_with_closest": any_consistent}
@@ -278,6 +290,13 @@ def cpu_baseline(verts, tris, sph, rays, gpu_hits, budget_s):
     base = {"value": round(mrays, 6), "unit": "Mrays/s", "cores": cores, "kind": kind,
             "sample": "first %d rays of the same batch, same scene (10M-class soup incl. the O(#spheres) linear sphere "
                       "loop of include/scene.h:142-144), %.1f s wall" % (n, dt)}
+    # the reference's own thread count (numWorkers = 8, src/scheduler.cpp:20) on the same sample
+    if cores != 8:
+        t0 = time.perf_counter()
+        (cpu.throughput(rays[:n], 8) if kind == "reference" else cpu.intersect(rays[:n], 0, nthreads=8))
+        dt8 = max(time.perf_counter() - t0, 1e-4)
+        base["at_8_threads"] = {"value": round(n / dt8 / 1e6, 6), "unit": "Mrays/s", "cores": 8,
+                                "sample": "the same %d rays, %.1f s wall" % (n, dt8)}
     # the same sample without spheres: the BVH part alone (BASELINE.md plan)
     if len(sph):
         del cpu
@@ -295,8 +314,15 @@ def cpu_baseline(verts, tris, sph, rays, gpu_hits, budget_s):
             if dt2 >= budget_s / 6 or n2 >= len(rays):
                 break
             n2 = min(len(rays), 1 << int(np.log2(n2 * min(64.0, max(2.0, 0.4 * budget_s / dt2)))))
-        base["triangles_only"] = {"value": round(n2 / dt2 / 1e6, 6), "unit": "Mrays/s",
+        base["triangles_only"] = {"value": round(n2 / dt2 / 1e6, 6), "unit": "Mrays/s", "cores": cores,
                                   "sample": "first %d rays, spheres removed, %.1f s wall" % (n2, dt2)}
+        if cores != 8:
+            t0 = time.perf_counter()
+            run2_8 = (lambda r: cpu2.throughput(r, 8)) if kind == "reference" else (lambda r: cpu2.intersect(r, 0, nthreads=8))
+            run2_8(rays[:n2])
+            dt28 = max(time.perf_counter() - t0, 1e-4)
+            base["triangles_only"]["at_8_threads"] = {"value": round(n2 / dt28 / 1e6, 6), "unit": "Mrays/s", "cores": 8,
+                                                      "sample": "the same %d rays, %.1f s wall" % (n2, dt28)}
     return base, parity
 
 

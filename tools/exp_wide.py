@@ -27,14 +27,14 @@ for var in variants:
     a.intersect_closest(rays, flags, out=hits); torch.cuda.synchronize()
     a.profile(True); a.profile_read()
     t0 = time.perf_counter()
-    for _ in range(3): a.intersect_closest(rays, flags, out=hits)
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+    for _ in range(6): a.intersect_closest(rays, flags, out=hits)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 6
     p = a.profile_read(); a.profile(False)
     h = hits.view(torch.int32).clone()
     if ref is None: ref = h
     nd = (h != ref).any(1).sum().item()
     print("%-60s build %.1fs depth %d: step %.3f ms  main %.3f  other %.3f  sort %.3f -> %.1f Mrays/s  diff=%d  MB=%.0f"
-          % (var, tb, a.wide_depth, dt * 1e3, p['ms_triangles'] / 3, p['ms_spheres'] / 3, p['ms_sort'] / 3,
+          % (var, tb, a.wide_depth, dt * 1e3, p['ms_triangles'] / 6, p['ms_spheres'] / 6, p["ms_sort"] / 6,
              rays_n / dt / 1e6, nd, a.device_bytes / 1e6), flush=True)
     a.close()
     for k in keys: os.environ.pop(k, None)

@@ -13,6 +13,8 @@ python3 tools/rocpd_summary.py gpurun_out/prof_$tag/bench_results.db > gpurun_ou
 : > gpurun_out/${tag}_pmc.txt
 for pass in "fetch:FETCH_SIZE SQ_WAVES" "write:WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
             "rdreq:TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_REQ_sum" \
+            "sizes:TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum TCC_READ_SECTORS_sum" \
+            "dram:TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_DRAM_32B_sum TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_WRITE_DRAM_32B_sum" \
             "sq:SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES" \
             "tcp:TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_THREAD_CYCLES_VALU"; do
     name=${pass%%:*}; ctrs=${pass#*:}

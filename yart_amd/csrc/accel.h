@@ -32,6 +32,7 @@ struct YartAccel {
     void* dSurfRows = nullptr;        // hit post-processing (yart_accel_set_surface_data)
     void* dSurfSpheres = nullptr;
     bool hasWide = false;
+    bool wideMergedRows = false;       // rowsA | rowsBC of a primitive in one 64-byte record (dWideRowsA), dWideRowsBC unused
     size_t wideNodes = 0, widePrims = 0;   // array sizes; the device copy is the only one kept
     int wideDepth = 0;
     size_t deviceBytes = 0;

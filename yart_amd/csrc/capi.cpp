@@ -203,7 +203,8 @@ int runIntersect(YartAccel* a, const Launch& L, const CallScratch* given)
         std::memset(&W, 0, sizeof W);
         W.nodes = static_cast<const float4*>(a->dWideNodes);
         W.rowsA = static_cast<const float4*>(a->dWideRowsA);
-        W.rowsBC = static_cast<const float4*>(a->dWideRowsBC);
+        if (a->wideMergedRows) { W.rowsBC = W.rowsA + 1; W.rowShift = 2; W.bcStride = 4; }
+        else { W.rowsBC = static_cast<const float4*>(a->dWideRowsBC); W.rowShift = 0; W.bcStride = 2; }
         W.rays = P.rays; W.perm = perm; W.n = n;
         W.hits = P.hits; W.occluded = P.occluded; W.counts = P.counts;
         W.workCounter = slot0;
@@ -335,8 +336,23 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
     if (st == YART_OK) st = upload(&a->dSphIndex, sph.index.data(), sph.index.size() * sizeof(uint32_t), a->deviceBytes);
     if (st == YART_OK && wantWide) {
         st = upload(&a->dWideNodes, wide.nodes.data(), wide.nodes.size() * sizeof(yart::WideNode), a->deviceBytes);
-        if (st == YART_OK) st = upload(&a->dWideRowsA, wide.rowsA.data(), wide.rowsA.size() * sizeof(float), a->deviceBytes);
-        if (st == YART_OK) st = upload(&a->dWideRowsBC, wide.rowsBC.data(), wide.rowsBC.size() * sizeof(float), a->deviceBytes);
+        const char* merged = std::getenv("YART_WIDE_MERGED_ROWS");
+        a->wideMergedRows = merged && merged[0] == '1';
+        if (a->wideMergedRows) {
+            // one 64-byte record per primitive: first-stage row, the two second-stage rows, 16 bytes unused
+            const size_t np = wide.rowsA.size() / 4;
+            std::vector<float> rec(np * 16, 0.0f);
+            yart::parallelChunks(np, yart::buildThreads(), size_t(1) << 16, [&](size_t b, size_t e) {
+                for (size_t i = b; i < e; ++i) {
+                    std::memcpy(&rec[i * 16], &wide.rowsA[i * 4], 16);
+                    std::memcpy(&rec[i * 16 + 4], &wide.rowsBC[i * 8], 32);
+                }
+            });
+            if (st == YART_OK) st = upload(&a->dWideRowsA, rec.data(), rec.size() * sizeof(float), a->deviceBytes);
+        } else {
+            if (st == YART_OK) st = upload(&a->dWideRowsA, wide.rowsA.data(), wide.rowsA.size() * sizeof(float), a->deviceBytes);
+            if (st == YART_OK) st = upload(&a->dWideRowsBC, wide.rowsBC.data(), wide.rowsBC.size() * sizeof(float), a->deviceBytes);
+        }
         a->hasWide = (st == YART_OK);
         a->wideNodes = wide.nodes.size();
         a->widePrims = wide.rowsA.size() / 4;
@@ -533,8 +549,14 @@ int yart_accel_get_wide(const YartAccel* a, void* nodes_out, void* rows_a_out, v
     DeviceGuard guard(a->device);
     hipError_t e = hipSuccess;
     if (nodes_out && a->wideNodes) e = hipMemcpy(nodes_out, a->dWideNodes, a->wideNodes * sizeof(yart::WideNode), hipMemcpyDeviceToHost);
-    if (e == hipSuccess && rows_a_out && a->widePrims) e = hipMemcpy(rows_a_out, a->dWideRowsA, a->widePrims * 16, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && rows_bc_out && a->widePrims) e = hipMemcpy(rows_bc_out, a->dWideRowsBC, a->widePrims * 32, hipMemcpyDeviceToHost);
+    if (a->wideMergedRows) {
+        const char* rec = static_cast<const char*>(a->dWideRowsA);
+        if (e == hipSuccess && rows_a_out && a->widePrims) e = hipMemcpy2D(rows_a_out, 16, rec, 64, 16, a->widePrims, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && rows_bc_out && a->widePrims) e = hipMemcpy2D(rows_bc_out, 32, rec + 16, 64, 32, a->widePrims, hipMemcpyDeviceToHost);
+    } else {
+        if (e == hipSuccess && rows_a_out && a->widePrims) e = hipMemcpy(rows_a_out, a->dWideRowsA, a->widePrims * 16, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && rows_bc_out && a->widePrims) e = hipMemcpy(rows_bc_out, a->dWideRowsBC, a->widePrims * 32, hipMemcpyDeviceToHost);
+    }
     if (e != hipSuccess) return failHip(e, "hipMemcpy D2H");
     return YART_OK;
 }

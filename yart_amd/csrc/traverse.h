@@ -57,6 +57,8 @@ struct WideParams {
     uint32_t nodeMin;
     uint32_t maxBlocksPerCU;    // 0 = as many as fit (8)
     uint32_t chunk;             // rays a wave takes from its range counter at a time (multiple of 64)
+    uint32_t rowShift;          // float4 index of primitive p's first-stage row in rowsA = p << rowShift (0: dense rows, 2: one 64-byte record per primitive)
+    uint32_t bcStride;          // float4 index of its second-stage rows in rowsBC = p * bcStride (2: dense, 4: the same 64-byte record)
 };
 
 hipError_t launchTraceWide(const WideParams& P, bool any, bool count, bool persistent, int numCUs,

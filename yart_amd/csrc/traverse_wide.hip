@@ -254,11 +254,11 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
             pend = kIdle;
             const uint32_t cnt = ((leaf >> 27) & 7u) + 1u;
             const uint32_t first = leaf & 0x07FFFFFFu;
-            const float4* blk = P.rowsA + first;
+            const float4* blk = P.rowsA + ((size_t)first << P.rowShift);
             bool stop = false;
             if ((leaf & kWideSphereBit) == 0) {
                 for (uint32_t i = 0; i < cnt; ++i) {
-                    const float4 A = blk[i];
+                    const float4 A = blk[(size_t)i << P.rowShift];
                     if (COUNT) ++cTri;
                     // include/triaccel.h:169-201
                     const uint32_t kw = __float_as_uint(A.w);
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
                     // order this tree finds them in.
                     const bool tie = !ANY && t == tTri && (int32_t)(kw >> 2) < primTri;
                     if (!((bound > t || tie) && t > 0.0001f)) continue;
-                    const float4 B = P.rowsBC[(size_t)(first + i) * 2], C = P.rowsBC[(size_t)(first + i) * 2 + 1];
+                    const float4 B = P.rowsBC[(size_t)(first + i) * P.bcStride], C = P.rowsBC[(size_t)(first + i) * P.bcStride + 1];
                     if (COUNT) ++cStage2;
                     const float phu = ou + t * du;
                     const float phv = ov + t * dv;
@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
                 }
             } else {
                 for (uint32_t i = 0; i < cnt; ++i) {
-                    const float4 S = blk[i];
+                    const float4 S = blk[(size_t)i << P.rowShift];
                     if (COUNT) ++cSph;
                     // include/sphere.h:63-97
                     const float opx = S.x - r.ox, opy = S.y - r.oy, opz = S.z - r.oz;
@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
                     // a sphere whose float t lies beyond the best triangle cannot be the result
                     // (the triangle is strictly closer); beyond the best sphere neither
                     if (f > fminf(tTri, F)) continue;
-                    const int32_t idx = (int32_t)__float_as_uint(P.rowsBC[(size_t)(first + i) * 2].x);
+                    const int32_t idx = (int32_t)__float_as_uint(P.rowsBC[(size_t)(first + i) * P.bcStride].x);
                     if (COUNT) ++cStage2;
                     const bool below = t < (double)f;
                     if (minS < 0 || f < F) { F = f; minS = idx; maxL = below ? idx : -1; }

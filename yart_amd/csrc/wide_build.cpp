@@ -523,6 +523,91 @@ private:
     uint32_t jobSpan_ = 0;
 };
 
+// Node order in memory.  The emitter writes nodes depth first (a node, then the subtrees of its
+// children one after the other).  What a fetch beyond L2 moves on MI355X is a 128-byte line = TWO nodes
+// (tools/calib_fetch.hip: a scattered 64-byte read is a 128-byte request to memory), so which node shares
+// a node's line decides whether the second half of every miss is useful:
+//   mode 0  depth first as emitted (a node's line mate is its first child, or an unrelated subtree's end)
+//   mode 1  a node shares its line with its largest interior child (the one a ray that visits the node
+//           most likely visits next): the dependent fetch after a miss is already in L2
+//   mode 2  the interior children of a node are stored side by side (siblings share lines)
+// Lines follow one another depth first in every mode.  nodes[0] stays the root.
+float childArea(const WideNode& w, int c)
+{
+    const float dx = (float(w.qhi[0][c]) - float(w.qlo[0][c])) * w.scale[0];
+    const float dy = (float(w.qhi[1][c]) - float(w.qlo[1][c])) * w.scale[1];
+    const float dz = (float(w.qhi[2][c]) - float(w.qlo[2][c])) * w.scale[2];
+    if (!(dx >= 0.0f && dy >= 0.0f && dz >= 0.0f)) return -1.0f;
+    return dx * dy + dy * dz + dz * dx;
+}
+
+void relayout(WideBvh& bvh, int mode)
+{
+    const size_t n = bvh.nodes.size();
+    if (mode == 0 || n < 3) return;
+    constexpr uint32_t kUnset = 0xFFFFFFFFu;
+    std::vector<uint32_t> newOf(n, kUnset), oldAt;
+    oldAt.reserve(n);
+    auto interiorKids = [&](uint32_t x, uint32_t* kids, float* area) {      // sorted by area, largest first
+        int k = 0;
+        const WideNode& w = bvh.nodes[x];
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t r = w.ref[c];
+            if (r == kWideNone || (r & kWideLeafBit)) continue;
+            kids[k] = r;
+            area[k] = childArea(w, c);
+            ++k;
+        }
+        for (int i = 1; i < k; ++i)
+            for (int j = i; j > 0 && area[j] > area[j - 1]; --j) { std::swap(area[j], area[j - 1]); std::swap(kids[j], kids[j - 1]); }
+        return k;
+    };
+    auto place = [&](uint32_t x) { newOf[x] = static_cast<uint32_t>(oldAt.size()); oldAt.push_back(x); };
+    std::vector<uint32_t> stack;
+    stack.push_back(0u);
+    uint32_t kids[4];
+    float area[4];
+    if (mode == 1) {
+        while (!stack.empty()) {
+            const uint32_t x = stack.back();
+            stack.pop_back();
+            place(x);
+            int k = interiorKids(x, kids, area);
+            if ((oldAt.size() & 1u) == 0u || k == 0) {           // x took the second half of a line, or has no interior child
+                for (int i = k - 1; i >= 0; --i) stack.push_back(kids[i]);
+                continue;
+            }
+            const uint32_t heavy = kids[0];
+            place(heavy);                                        // second half of x's line
+            for (int i = k - 1; i >= 1; --i) stack.push_back(kids[i]);
+            uint32_t hk[4];
+            float ha[4];
+            const int m = interiorKids(heavy, hk, ha);
+            for (int i = m - 1; i >= 0; --i) stack.push_back(hk[i]);       // the heavy child's subtree comes first
+        }
+    } else {
+        place(0u);
+        while (!stack.empty()) {
+            const uint32_t x = stack.back();
+            stack.pop_back();
+            const int k = interiorKids(x, kids, area);
+            for (int i = 0; i < k; ++i) place(kids[i]);          // siblings side by side
+            for (int i = k - 1; i >= 0; --i) stack.push_back(kids[i]);
+        }
+    }
+    if (oldAt.size() != n) return;                               // unreachable nodes: keep the emitted order
+    std::vector<WideNode> out(n);
+    parallelChunks(n, buildThreads(), size_t(1) << 14, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            WideNode w = bvh.nodes[oldAt[i]];
+            for (auto& r : w.ref)
+                if (r != kWideNone && !(r & kWideLeafBit)) r = newOf[r];
+            out[i] = w;
+        }
+    });
+    bvh.nodes.swap(out);
+}
+
 } // namespace
 
 int buildWideBvh(const float* verts, size_t nVerts, const int32_t* tris, size_t nTris,
@@ -536,20 +621,77 @@ int buildWideBvh(const float* verts, size_t nVerts, const int32_t* tris, size_t 
         err = "wide BVH: more than 2^30 primitives of one kind";
         return YART_ERR_INVALID_ARGUMENT;
     }
-    std::vector<BPrim> prims(nTris + nSpheres);
+    // Pre-splitting (YART_WIDE_PRESPLIT=k): the box of a triangle is mostly empty space, and every ray
+    // through that space pays a node's slot and a plane-row test.  A triangle is cut into up to k slabs
+    // across the longest axis of its box and enters the build once per slab, with the box of its part
+    // inside the slab; each part's leaf tests the whole triangle (same rows, same result), so a ray
+    // that meets two parts finds the same hit twice.
+    const int presplit = std::max(1, std::min(8, envInt("YART_WIDE_PRESPLIT", 1)));
+    const size_t perTri = static_cast<size_t>(presplit);
+    std::vector<BPrim> prims(nTris * perTri + nSpheres);
     parallelChunks(nTris, buildThreads(), size_t(1) << 16, [&](size_t b, size_t e) {
         for (size_t i = b; i < e; ++i) {
             const int32_t* t = tris + i * 5;
-            BPrim& p = prims[i];
-            const float* v0 = verts + static_cast<size_t>(t[0]) * 3;
-            std::memcpy(p.lo, v0, 12);
-            std::memcpy(p.hi, v0, 12);
-            for (int k = 1; k < 3; ++k) {
-                const float* v = verts + static_cast<size_t>(t[k]) * 3;
-                for (int a = 0; a < 3; ++a) { p.lo[a] = std::min(p.lo[a], v[a]); p.hi[a] = std::max(p.hi[a], v[a]); }
+            const float* vv[3] = { verts + static_cast<size_t>(t[0]) * 3, verts + static_cast<size_t>(t[1]) * 3,
+                                   verts + static_cast<size_t>(t[2]) * 3 };
+            BPrim whole;
+            std::memcpy(whole.lo, vv[0], 12);
+            std::memcpy(whole.hi, vv[0], 12);
+            for (int k = 1; k < 3; ++k)
+                for (int a = 0; a < 3; ++a) { whole.lo[a] = std::min(whole.lo[a], vv[k][a]); whole.hi[a] = std::max(whole.hi[a], vv[k][a]); }
+            whole.id = static_cast<uint32_t>(i);
+            BPrim* out = &prims[i * perTri];
+            int made = 0;
+            int axis = 0;
+            for (int a = 1; a < 3; ++a) if (whole.hi[a] - whole.lo[a] > whole.hi[axis] - whole.lo[axis]) axis = a;
+            const double ext = static_cast<double>(whole.hi[axis]) - whole.lo[axis];
+            if (presplit > 1 && ext > 0.0 && ext < 1e30) {
+                for (int sidx = 0; sidx < presplit; ++sidx) {
+                    // slab [p0, p1] widened a little: parts overlap, so no point of the triangle falls between two boxes
+                    const double margin = ext * 1e-5;
+                    const double p0 = whole.lo[axis] + ext * sidx / presplit - margin;
+                    const double p1 = whole.lo[axis] + ext * (sidx + 1) / presplit + margin;
+                    double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+                    bool any = false;
+                    auto add = [&](const double* q) {
+                        any = true;
+                        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], q[a]); hi[a] = std::max(hi[a], q[a]); }
+                    };
+                    for (int k = 0; k < 3; ++k) {                 // every edge: end points inside the slab, crossings of its planes
+                        const float* A = vv[k];
+                        const float* B = vv[(k + 1) % 3];
+                        const double a0 = A[axis], b0 = B[axis];
+                        if (a0 >= p0 && a0 <= p1) { const double q[3] = { A[0], A[1], A[2] }; add(q); }
+                        for (const double pl : { p0, p1 }) {
+                            if ((a0 < pl && b0 > pl) || (a0 > pl && b0 < pl)) {
+                                const double w = (pl - a0) / (b0 - a0);
+                                double q[3];
+                                for (int a = 0; a < 3; ++a) q[a] = A[a] + (static_cast<double>(B[a]) - A[a]) * w;
+                                q[axis] = pl;
+                                add(q);
+                            }
+                        }
+                    }
+                    if (!any) continue;
+                    BPrim& p = out[made++];
+                    for (int a = 0; a < 3; ++a) {                 // outward to float, a relative hair wider, never beyond the whole box
+                        const double m = 1e-6 * (std::fabs(lo[a]) + std::fabs(hi[a])) + 1e-30;
+                        float l = static_cast<float>(lo[a] - m), h = static_cast<float>(hi[a] + m);
+                        if (static_cast<double>(l) > lo[a] - m) l = std::nextafter(l, -std::numeric_limits<float>::infinity());
+                        if (static_cast<double>(h) < hi[a] + m) h = std::nextafter(h, std::numeric_limits<float>::infinity());
+                        p.lo[a] = std::max(l, whole.lo[a]);
+                        p.hi[a] = std::min(h, whole.hi[a]);
+                    }
+                    p.id = whole.id;
+                }
             }
-            for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * p.lo[a] + 0.5f * p.hi[a];
-            p.id = static_cast<uint32_t>(i);
+            if (made == 0) out[made++] = whole;
+            for (int f = 0; f < made; ++f)
+                for (int a = 0; a < 3; ++a) out[f].c[a] = 0.5f * out[f].lo[a] + 0.5f * out[f].hi[a];
+            for (int f = made; f < presplit; ++f) {              // unused part slots: removed below
+                out[f].lo[0] = std::numeric_limits<float>::quiet_NaN();
+                out[f].hi[0] = 0.0f;
+            }
         }
     });
     parallelChunks(nSpheres, buildThreads(), size_t(1) << 16, [&](size_t b, size_t e) {
@@ -558,7 +700,7 @@ int buildWideBvh(const float* verts, size_t nVerts, const int32_t* tris, size_t 
             // fp64 sphere test (include/sphere.h:63-97) accepts
             const float* s = spheres + i * 4;
             const float r = std::fabs(s[3]);
-            BPrim& p = prims[nTris + i];
+            BPrim& p = prims[nTris * perTri + i];
             for (int a = 0; a < 3; ++a) {
                 const float margin = 1e-5f * (std::fabs(s[a]) + r) + 1e-30f;
                 p.lo[a] = s[a] - r - margin;
@@ -592,7 +734,10 @@ int buildWideBvh(const float* verts, size_t nVerts, const int32_t* tris, size_t 
             err = "wide BVH: more than 2^27 - 1 primitives";
             return YART_ERR_INVALID_ARGUMENT;
         }
-        if (3 * out.depth + 1 <= kWideStack) return YART_OK;
+        if (3 * out.depth + 1 <= kWideStack) {
+            relayout(out, envInt("YART_WIDE_LAYOUT", 0));
+            return YART_OK;
+        }
         // SAH produced a tree too deep for the traversal stack: rebuild balanced (object median)
     }
     err = "wide BVH deeper than the traversal stack allows";
