@@ -254,6 +254,75 @@ int yart_surface_dev(YartAccel* accel, const YartRay* d_rays, const YartHit* d_h
 /* Host buffers; synchronous. */
 int yart_surface(YartAccel* accel, const YartRay* rays, const YartHit* hits, size_t n, YartSurface* out);
 
+/* ---- Wavefront driver, device resident ----------------------------------------------
+ * Replaces the per-pixel synchronous loop of the reference's renderer -- TileTask::run -> trace()
+ * (src/renderer.cpp:29-136, :146-153), which calls Scene::intersect / intersectShadow one ray at a time
+ * -- by path queues that never leave HBM: a pool of `slots` paths, each with its pending ray, hit,
+ * surface record (row K), shadow ray and occlusion flag, advanced one bounce per iteration by
+ *     closest-hit batch -> yart_surface_dev -> shade kernel -> any-hit batch -> apply kernel,
+ * every batch `slots` rays wide.  A path that ends frees its slot; with `regenerate` the next
+ * iteration starts a new camera path there, so batches stay full until the frame's paths run out
+ * (the rays of one batch then come from different bounces: the incoherent stream BASELINE's metric is
+ * quoted on); without it a pool is traced bounce by bounce to the end before the next one starts
+ * (per-bounce batch statistics).
+ *
+ * The integrator that runs on the device is the diffuse path tracer of BASELINE configs[2]: trace()'s
+ * structure with one point light and Lambertian surfaces (camera sample with pixel jitter
+ * include/camera.h:24-31; light sample include/light.h:41-52; shadow ray from P + wi EPS, :101-102;
+ * Russian roulette on the weight's luminance, :113-115; cosine-weighted bounce in the hit's Frame,
+ * include/frame.h:18-32; next ray from P + dir EPS, :129; colour x 1/spp per sample, :132).  Its random
+ * numbers are a counter-based hash of (seed, pixel number y*width+x as in :33, sample, bounce, purpose),
+ * not the reference's std::mt19937_64 stream: a path's result does not depend on which slot or batch
+ * traced it, and the frame is reproducible bit for bit (samples of a pixel are summed in order).  A
+ * renderer whose shading stays on the host (the reference's BSDFs, lights and Rng) uses
+ * yart_amd/cxx/wavefront.hpp over the same device calls instead. */
+typedef struct YartWavefront YartWavefront;
+
+typedef struct YartDiffuseJob {
+    float cam_pos[3];           /* Camera::position_ */
+    float cam_dir[3];           /* Camera::direction_ (unit) */
+    float cam_right[3];         /* Camera::right_ = cross(dir, up) * (width * fov / height) */
+    float cam_up[3];            /* Camera::up_    = normal(cross(right, dir)) * fov */
+    int32_t width, height;
+    int32_t spp;                /* samples per pixel (the reference: 4096, src/renderer.cpp:36) */
+    int32_t max_depth;          /* closest-hit rays per path at most (the reference: 10, :58) */
+    float light_pos[3];         /* PointLight */
+    float light_intensity[3];
+    float albedo[3];            /* Lambertian reflectance of every surface */
+    uint32_t seed;
+    const uint32_t* d_pixels;   /* device array of pixel numbers y*width+x to render (a rank's share of the
+                                   tile list, yart_tiles_pixels), or NULL for all pixels in row-major order */
+    size_t n_pixels;            /* entries of d_pixels; ignored when it is NULL */
+    int32_t regenerate;         /* 1: refill freed slots every iteration; 0: pool by pool, bounce by bounce */
+    unsigned flags;             /* yart_flags for the intersect calls (YART_SORT_RAYS ...) */
+} YartDiffuseJob;
+
+typedef struct YartWavefrontIter {   /* one iteration = one bounce of every path in flight */
+    uint64_t closest_rays;      /* live paths traced by the closest-hit batch */
+    uint64_t shadow_rays;       /* of them hit a surface and sent a shadow ray */
+    float ms_closest;           /* closest-hit batch (sort + traversal), HIP events on the stream */
+    float ms_surface;           /* yart_surface_dev */
+    float ms_shadow;            /* any-hit batch */
+    float ms_shade;             /* generate + shade + apply kernels */
+} YartWavefrontIter;
+
+typedef struct YartWavefrontStats {
+    uint64_t paths, closest_rays, shadow_rays, iterations;
+    double ms_total;            /* wall time of the call, host clock around a final synchronise */
+    double ms_closest, ms_surface, ms_shadow, ms_shade;
+} YartWavefrontStats;
+
+/* slots: paths in flight (>= 1; 2^20 .. 2^23 fills the GPU).  The accel must have its surface data
+ * (yart_accel_set_surface_data).  HBM: 224 bytes per slot + 16 bytes per path of a sample slab. */
+int yart_wavefront_create(YartAccel* accel, size_t slots, YartWavefront** out);
+void yart_wavefront_destroy(YartWavefront* wf);
+/* Renders job->spp samples of every listed pixel into d_rgb (device, 3 floats per listed pixel, in
+ * list order; overwritten).  iters / max_iters: optional per-iteration records (the first max_iters).
+ * Synchronous: returns when the frame is in d_rgb. */
+int yart_wavefront_render_diffuse(YartWavefront* wf, const YartDiffuseJob* job, float* d_rgb,
+                                  YartWavefrontStats* stats, YartWavefrontIter* iters, size_t max_iters,
+                                  void* stream);
+
 /* ---- Scene ingestion -------------------------------------------------------------
  * Replaces Scene::loadFromObj(folder, file) (src/scene.cpp:159-298) and, beneath it, the bundled
  * tinyobjloader's LoadObj / LoadMtl (external/tinyobjloader/tiny_obj_loader.h:838-1133, :587-813):

@@ -378,6 +378,8 @@ bool sceneIntersectShadow(const Scene& sc, const Ray& r, Counters* c)
 //     (distance pruning), final acceptance still tests tNear < ray.maxT.
 // A "node" count is one 32-byte child record fetched.
 // ---------------------------------------------------------------------------
+constexpr float kCullSlack = 1.0f + 0x1p-18f;
+
 template <bool shadow>
 bool traverseEngine(const Scene& sc, const Ray& r, Hit& h, Counters* c)
 {
@@ -387,14 +389,14 @@ bool traverseEngine(const Scene& sc, const Ray& r, Hit& h, Counters* c)
     bool hit = false;
     // the root sits in pair 0 next to an empty leaf: one 64-byte fetch = 2 records
     if (c) c->nodes += 2;
-    if (!slab(sc.nodes[0].b, r, shadow ? r.tmax : h.t)) return false;
+    if (!slab(sc.nodes[0].b, r, shadow ? r.tmax : h.t * kCullSlack)) return false;
     uint32_t cur = 0;
     for (;;) {
         const Node& n = sc.nodes[cur];
         if (n.splitAxis != 3) {
             uint32_t l = cur + 1, rr = n.offset;
             if (c) c->nodes += 2;
-            float bound = shadow ? r.tmax : h.t;
+            float bound = shadow ? r.tmax : h.t * kCullSlack;      // as yart_amd/csrc/traverse.hip
             bool hl = slab(sc.nodes[l].b, r, bound);
             bool hr = slab(sc.nodes[rr].b, r, bound);
             uint32_t first = l, second = rr;
@@ -455,7 +457,7 @@ bool traverseWide(const WideNodeRec* nodes, const float* rowsA, const float* row
         if (!(cur & kLeaf)) {
             const WideNodeRec& n = nodes[cur];
             if (c) c->nodes += 4;
-            const float bound = shadow ? r.tmax : fmin2(tTri, F);
+            const float bound = (shadow ? r.tmax : fmin2(tTri, F)) * kCullSlack;     // as traverse_wide.hip
             float tn[4];
             uint32_t rf[4];
             int nHit = 0;

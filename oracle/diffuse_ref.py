@@ -1,0 +1,195 @@
+"""TEST INFRASTRUCTURE -- CPU restatement of the diffuse path integrator that the device wavefront
+driver runs (yart_amd/csrc/wavefront.hip), on top of the oracle's intersection (oracle/cpu_ref.cpp,
+pinned to the real reference).  Only tests / measurement scripts may import this.
+
+It is the synchronous per-pixel loop of the reference's trace() (src/renderer.cpp:29-136) with one point
+light and Lambertian surfaces, evaluated for all paths at once with numpy float32 arithmetic in exactly
+the device code's operation order (+, -, *, /, sqrt only: every operation rounds the same on both sides),
+so a device frame can be compared bit for bit.  Random numbers: the same counter-based hash."""
+import numpy as np
+
+f32 = np.float32
+EPS = f32(1e-4)           # include/constants.h:7
+INV_PI = f32(0.318309886)
+INF = f32(np.inf)
+
+
+def pcg(v):
+    v = np.asarray(v, np.uint64) & np.uint64(0xFFFFFFFF)
+    state = (v * np.uint64(747796405) + np.uint64(2891336453)) & np.uint64(0xFFFFFFFF)
+    shift = (state >> np.uint64(28)) + np.uint64(4)
+    word = (((state >> shift) ^ state) * np.uint64(277803737)) & np.uint64(0xFFFFFFFF)
+    return ((word >> np.uint64(22)) ^ word) & np.uint64(0xFFFFFFFF)
+
+
+def rnd(key, dim):
+    dim = np.asarray(dim, np.uint64)
+    h = pcg((key + dim * np.uint64(0x632BE5AB)) & np.uint64(0xFFFFFFFF))
+    return ((h >> np.uint64(8)).astype(np.float64) * 2.0 ** -24).astype(f32)
+
+
+def path_key(seed, pixel, sample):
+    a = pcg(np.uint64(seed) ^ np.uint64(0x9E3779B9))
+    b = pcg((a + np.asarray(pixel, np.uint64)) & np.uint64(0xFFFFFFFF))
+    return pcg((b + np.asarray(sample, np.uint64)) & np.uint64(0xFFFFFFFF))
+
+
+def camera_basis(pos, direction, width, height, fov):
+    """Camera::Camera (include/camera.h:9-22) in fp32 -> pos, dir, right, up for YartDiffuseJob."""
+    pos = np.asarray(pos, f32)
+    d = np.asarray(direction, f32)
+    d = (d * (f32(1.0) / np.sqrt((d * d).sum(dtype=f32)))).astype(f32)
+    up = np.array([0, 1, 0], f32)
+    right = (np.cross(d, up).astype(f32) * f32(f32(width) * f32(fov) / f32(height))).astype(f32)
+    upv = np.cross(right, d).astype(f32)
+    upv = (upv * (f32(1.0) / np.sqrt((upv * upv).sum(dtype=f32))) * f32(fov)).astype(f32)
+    return pos, d, right, upv
+
+
+def _dot(a, b):
+    return (a[:, 0] * b[:, 0] + a[:, 1] * b[:, 1]) + a[:, 2] * b[:, 2]
+
+
+class Normals:
+    """Geometric normal per hit: Triangle::getNormal (include/triangle.h:158-164) /
+    Sphere::intersect (include/sphere.h:80-83), in the order yart_accel_set_surface_data and the
+    surface kernel evaluate them."""
+
+    def __init__(self, oracle, verts, tris, spheres):
+        verts = np.asarray(verts, f32).reshape(-1, 3)
+        tris = np.asarray(tris, np.int32).reshape(-1, 5)
+        self.spheres = np.asarray(spheres, f32).reshape(-1, 4)
+        order = oracle.leaf_order().astype(np.int64)          # leaf slot -> input triangle
+        p0, p1, p2 = (verts[tris[order, k]] for k in range(3))
+        e1, e2 = (p1 - p0).astype(f32), (p2 - p0).astype(f32)
+        cx = e1[:, 1] * e2[:, 2] - e1[:, 2] * e2[:, 1]
+        cy = e1[:, 2] * e2[:, 0] - e1[:, 0] * e2[:, 2]
+        cz = e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = f32(1.0) / np.sqrt((cx * cx + cy * cy) + cz * cz)
+            self.tri_n = np.stack([cx * inv, cy * inv, cz * inv], 1).astype(f32)
+
+    def __call__(self, rays, hits):
+        prim = hits["prim"]
+        n = np.zeros((len(prim), 3), f32)
+        t = prim >= 0
+        n[t] = self.tri_n[prim[t]]
+        s = prim <= -2
+        if s.any():
+            sp = self.spheres[-(prim[s] + 2)]
+            r = rays[s]
+            tt = hits["t"][s]
+            x = (r[:, 0] + r[:, 4] * tt) - sp[:, 0]
+            y = (r[:, 1] + r[:, 5] * tt) - sp[:, 1]
+            z = (r[:, 2] + r[:, 6] * tt) - sp[:, 2]
+            inv = f32(1.0) / np.sqrt((x * x + y * y) + z * z)
+            n[s] = np.stack([x * inv, y * inv, z * inv], 1)
+        return n
+
+
+def render(oracle, normals, cam, width, height, spp, max_depth, light_pos, light_intensity, albedo, seed,
+           pixels=None, nthreads=8, stats=None):
+    """-> float32 [n_pixels, 3] in pixel-list order (all pixels row-major when pixels is None)."""
+    pos, cdir, right, up = (np.asarray(a, f32) for a in cam)
+    light = np.asarray(light_pos, f32)
+    inten = np.asarray(light_intensity, f32)
+    alb = np.asarray(albedo, f32)
+    if pixels is None:
+        pixels = np.arange(width * height, dtype=np.uint32)
+    pixels = np.asarray(pixels, np.uint32)
+    npx = len(pixels)
+    inv_spp = f32(1.0) / f32(spp)
+    out = np.zeros((npx, 3), f32)
+    for s in range(spp):                                   # samples in order: finalColor += color * invMaxIter
+        key = path_key(seed, pixels, np.full(npx, s, np.uint64))
+        x = ((pixels % np.uint32(width)).astype(f32) + rnd(key, 0)) - f32(0.5)
+        y = ((pixels // np.uint32(width)).astype(f32) + rnd(key, 1)) - f32(0.5)
+        a = (x + f32(0.5)) / f32(width) - f32(0.5)
+        b = -(y + f32(0.5)) / f32(height) + f32(0.5)
+        d = np.empty((npx, 3), f32)
+        for c in range(3):
+            d[:, c] = (right[c] * a + up[c] * b) + cdir[c]
+        inv = f32(1.0) / np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2])
+        rays = np.zeros((npx, 8), f32)
+        rays[:, 0:3] = pos
+        rays[:, 4:7] = d * inv[:, None]
+        rays[:, 7] = INF
+        idx = np.arange(npx)                               # paths still alive -> pixel-list index
+        w = np.ones((npx, 3), f32)
+        color = np.zeros((npx, 3), f32)
+        for bounce in range(max_depth):
+            if len(idx) == 0:
+                break
+            hits = oracle.intersect(rays, mode=0, nthreads=nthreads)
+            if stats is not None:
+                stats.setdefault("closest", []).append((rays.copy(), hits.copy()))
+            hit = hits["prim"] != -1
+            idx, rays, hits, w, key = idx[hit], rays[hit], hits[hit], w[hit], key[hit]
+            if len(idx) == 0:
+                break
+            n = normals(rays, hits)
+            t = hits["t"]
+            P = (rays[:, 0:3] + rays[:, 4:7] * t[:, None]).astype(f32)
+            front = _dot(n, rays[:, 4:7]) < 0
+            nl = np.where(front[:, None], n, -n).astype(f32)
+            tl = (light[None] - P).astype(f32)
+            dist2 = (tl[:, 0] * tl[:, 0] + tl[:, 1] * tl[:, 1]) + tl[:, 2] * tl[:, 2]
+            dist = np.sqrt(dist2)
+            inv_d = f32(1.0) / dist
+            wi = (tl * inv_d[:, None]).astype(f32)
+            sh = np.zeros((len(idx), 8), f32)
+            sh[:, 0:3] = P + wi * EPS
+            sh[:, 4:7] = wi
+            sh[:, 7] = dist
+            occ = oracle.intersect_shadow(sh, mode=0, nthreads=nthreads)
+            if stats is not None:
+                stats.setdefault("shadow", []).append((sh.copy(), occ.copy()))
+            cos_l = np.abs(_dot(nl, wi))
+            pend = np.empty((len(idx), 3), f32)
+            for c in range(3):
+                pend[:, c] = w[:, c] * (alb[c] * INV_PI) * (inten[c] / dist2) * cos_l
+            clear = occ == 0
+            color[idx[clear]] = color[idx[clear]] + pend[clear]
+            dim = 2 + bounce * 32
+            q = (f32(0.2126) * w[:, 0] + f32(0.7152) * w[:, 1]) + f32(0.0722) * w[:, 2]
+            go = ~(rnd(key, dim + 3) > q) & (q > 0) & (bounce + 1 < max_depth)
+            idx, rays, P, nl, w, key, q = idx[go], rays[go], P[go], nl[go], w[go], key[go], q[go]
+            if len(idx) == 0:
+                break
+            w = (w / q[:, None]).astype(f32)
+            lx = np.zeros(len(idx), f32)
+            ly = np.zeros(len(idx), f32)
+            found = np.zeros(len(idx), bool)
+            for k in range(8):
+                ax = f32(2.0) * rnd(key, dim + 4 + 2 * k) - f32(1.0)
+                ay = f32(2.0) * rnd(key, dim + 5 + 2 * k) - f32(1.0)
+                ok = ~found & (ax * ax + ay * ay <= f32(1.0))
+                lx[ok], ly[ok] = ax[ok], ay[ok]
+                found |= ok
+            lz = np.sqrt(np.maximum(f32(0.0), (f32(1.0) - lx * lx) - ly * ly))
+            inv_n = f32(1.0) / np.sqrt((nl[:, 0] * nl[:, 0] + nl[:, 1] * nl[:, 1]) + nl[:, 2] * nl[:, 2])
+            nx, ny, nz = nl[:, 0] * inv_n, nl[:, 1] * inv_n, nl[:, 2] * inv_n
+            with np.errstate(divide="ignore", invalid="ignore"):
+                il_a = f32(1.0) / np.sqrt(nx * nx + nz * nz)
+                il_b = f32(1.0) / np.sqrt(ny * ny + nz * nz)
+            br = np.abs(nx) > np.abs(ny)
+            zero = np.zeros_like(nx)
+            fx = np.where(br, -nz * il_a, zero)
+            fy = np.where(br, zero, nz * il_b)
+            fz = np.where(br, nx * il_a, -ny * il_b)
+            sx = ny * fz - nz * fy
+            sy = nz * fx - nx * fz
+            sz = nx * fy - ny * fx
+            dd = np.empty((len(idx), 3), f32)
+            dd[:, 0] = (lx * sx + ly * fx) + lz * nx
+            dd[:, 1] = (lx * sy + ly * fy) + lz * ny
+            dd[:, 2] = (lx * sz + ly * fz) + lz * nz
+            go2 = lz != 0
+            idx, P, w, key, dd = idx[go2], P[go2], w[go2], key[go2], dd[go2]
+            w = (w * alb[None]).astype(f32)
+            rays = np.zeros((len(idx), 8), f32)
+            rays[:, 0:3] = P + dd * EPS
+            rays[:, 4:7] = dd
+            rays[:, 7] = INF
+        out = (out + color * inv_spp).astype(f32)
+    return out

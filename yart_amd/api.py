@@ -42,7 +42,30 @@ EXPORTS = [
     "yart_obj_num_materials", "yart_obj_num_spheres", "yart_obj_get", "yart_obj_mesh_name", "yart_obj_material_name",
     "yart_film_tonemap", "yart_film_write_bmp",
     "yart_accel_set_surface_data", "yart_surface_dev", "yart_surface",
+    "yart_wavefront_create", "yart_wavefront_destroy", "yart_wavefront_render_diffuse",
 ]
+
+
+class DiffuseJob(ctypes.Structure):
+    """YartDiffuseJob (include/yart_amd.h)."""
+    _fields_ = [("cam_pos", ctypes.c_float * 3), ("cam_dir", ctypes.c_float * 3), ("cam_right", ctypes.c_float * 3),
+                ("cam_up", ctypes.c_float * 3), ("width", ctypes.c_int32), ("height", ctypes.c_int32),
+                ("spp", ctypes.c_int32), ("max_depth", ctypes.c_int32), ("light_pos", ctypes.c_float * 3),
+                ("light_intensity", ctypes.c_float * 3), ("albedo", ctypes.c_float * 3), ("seed", ctypes.c_uint32),
+                ("d_pixels", ctypes.c_void_p), ("n_pixels", ctypes.c_size_t), ("regenerate", ctypes.c_int32),
+                ("flags", ctypes.c_uint)]
+
+
+class WavefrontIter(ctypes.Structure):
+    _fields_ = [("closest_rays", ctypes.c_uint64), ("shadow_rays", ctypes.c_uint64), ("ms_closest", ctypes.c_float),
+                ("ms_surface", ctypes.c_float), ("ms_shadow", ctypes.c_float), ("ms_shade", ctypes.c_float)]
+
+
+class WavefrontStats(ctypes.Structure):
+    _fields_ = [("paths", ctypes.c_uint64), ("closest_rays", ctypes.c_uint64), ("shadow_rays", ctypes.c_uint64),
+                ("iterations", ctypes.c_uint64), ("ms_total", ctypes.c_double), ("ms_closest", ctypes.c_double),
+                ("ms_surface", ctypes.c_double), ("ms_shadow", ctypes.c_double), ("ms_shade", ctypes.c_double)]
+
 
 SURFACE_DTYPE = np.dtype([("normal", np.float32, 3), ("t", np.float32), ("shading_normal", np.float32, 3),
                           ("u", np.float32), ("v", np.float32), ("prim", np.int32), ("mesh_idx", np.int32),
@@ -117,6 +140,11 @@ def lib():
     L.yart_accel_set_surface_data.argtypes = [_vp, _vp, _sz, _vp, _sz, _vp, _vp, _sz]
     L.yart_surface_dev.argtypes = [_vp, _vp, _vp, _sz, _vp, _vp]
     L.yart_surface.argtypes = [_vp, _vp, _vp, _sz, _vp]
+    L.yart_wavefront_create.argtypes = [_vp, _sz, ctypes.POINTER(_vp)]
+    L.yart_wavefront_destroy.argtypes = [_vp]
+    L.yart_wavefront_destroy.restype = None
+    L.yart_wavefront_render_diffuse.argtypes = [_vp, ctypes.POINTER(DiffuseJob), _vp, ctypes.POINTER(WavefrontStats),
+                                                ctypes.POINTER(WavefrontIter), _sz, _vp]
     L.yart_film_tonemap.argtypes = [_vp, _sz, _vp]
     L.yart_film_write_bmp.argtypes = [ctypes.c_char_p, _vp, ctypes.c_int32, ctypes.c_int32]
     L.yart_status_string.argtypes = [ctypes.c_int]
@@ -386,6 +414,59 @@ class Accel:
         occ = np.zeros(len(rays), np.uint8)
         _check(lib().yart_intersect_any(self._h, _p(rays), len(rays), _p(occ), flags))
         return occ
+
+
+class Wavefront:
+    """Device-resident path queues + the diffuse integrator (yart_wavefront_*)."""
+
+    def __init__(self, accel, slots):
+        self._h = None
+        h = _vp()
+        _check(lib().yart_wavefront_create(accel._h, int(slots), ctypes.byref(h)))
+        self._h = h
+        self.accel = accel
+        self.slots = int(slots)
+
+    def close(self):
+        if self._h:
+            lib().yart_wavefront_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render_diffuse(self, cam, width, height, spp, max_depth, light_pos, light_intensity, albedo, seed=1,
+                       pixels=None, regenerate=True, flags=YART_SORT_RAYS, max_iters=4096, stream=None):
+        """cam = (pos, dir, right, up) as Camera holds them (oracle/diffuse_ref.camera_basis or the C++ shim's
+        Camera).  pixels: optional int32/uint32 CUDA tensor of pixel numbers y*width+x.  -> (rgb [n,3] float32
+        CUDA tensor in pixel-list order, stats dict, list of per-iteration dicts)."""
+        import torch
+        job = DiffuseJob()
+        for name, v in (("cam_pos", cam[0]), ("cam_dir", cam[1]), ("cam_right", cam[2]), ("cam_up", cam[3]),
+                        ("light_pos", light_pos), ("light_intensity", light_intensity), ("albedo", albedo)):
+            setattr(job, name, (ctypes.c_float * 3)(*[float(x) for x in v]))
+        job.width, job.height, job.spp, job.max_depth = int(width), int(height), int(spp), int(max_depth)
+        job.seed = int(seed)
+        job.regenerate = 1 if regenerate else 0
+        job.flags = int(flags)
+        n = width * height
+        if pixels is not None:
+            if not (pixels.is_cuda and pixels.is_contiguous() and pixels.dtype in (torch.int32, torch.uint32)):
+                raise YartError("pixels must be a contiguous int32 CUDA tensor")
+            job.d_pixels = pixels.data_ptr()
+            job.n_pixels = pixels.numel()
+            n = pixels.numel()
+        rgb = torch.empty((n, 3), dtype=torch.float32, device="cuda:%d" % self.accel.device)
+        st = WavefrontStats()
+        its = (WavefrontIter * max_iters)()
+        _check(lib().yart_wavefront_render_diffuse(self._h, ctypes.byref(job), _vp(rgb.data_ptr()), ctypes.byref(st), its,
+                                                   max_iters, self.accel._stream(stream)))
+        stats = {k: getattr(st, k) for k, _ in WavefrontStats._fields_}
+        iters = [{k: getattr(its[i], k) for k, _ in WavefrontIter._fields_} for i in range(min(max_iters, int(st.iterations)))]
+        return rgb, stats, iters
 
 
 def hits_to_numpy(hits_tensor):

@@ -109,6 +109,8 @@ __device__ __forceinline__ bool finiteNonZero(float v)
     return (v != 0.0f) && (fabsf(v) < __builtin_inff());
 }
 
+constexpr float kCullSlack = 1.0f + 0x1p-18f;
+
 template <int PRIM, bool ANY, bool PRUNE, bool COUNT, bool PERSIST>
 __global__ void __launch_bounds__(kBlock) traceKernel(TraceParams P)
 {
@@ -234,7 +236,7 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceParams P)
                 const float4* p = P.pairs + (size_t)(cur & 0x1FFFFFFFu) * 4;
                 const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
                 const uint32_t axis = cur >> 29;
-                const float bound = (PRUNE && !ANY) ? tcur : r.tmax;
+                const float bound = (PRUNE && !ANY) ? tcur * kCullSlack : r.tmax;      // slack: see traverse_wide.hip
                 bool h0, h1;
                 if (__ballot(odd) != 0) {            // rare: some lane's ray can produce NaN plane distances
                     h0 = slabExact(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, bound);

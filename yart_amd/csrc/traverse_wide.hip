@@ -36,6 +36,12 @@ constexpr int kBlock = 256;
 constexpr int kLdsStack = 19;
 constexpr int kOvfStack = kWideStack - kLdsStack;
 constexpr uint32_t kIdle = kWideNone;
+// Nodes are culled against the best hit so far times this: the plane distances of slab4 carry the rounding
+// of the ray-side arithmetic (a few ulp), and a box whose computed entry lands one ulp beyond an equally
+// distant hit found earlier would otherwise be skipped or not depending on the order in which a wave
+// happened to find the two -- the result for a ray through a shared edge then changed from run to run.
+// The primitive tests keep the exact bound.  (oracle/cpu_ref.cpp traverseWide mirrors it.)
+constexpr float kCullSlack = 1.0f + 0x1p-18f;
 constexpr uint32_t kNeedPop = 0xFFFFFFFEu;       // "take the next stack entry": not a possible leaf reference (first + count <= 2^27 - 1)
 
 __device__ __forceinline__ uint32_t rangeBegin(uint32_t n, uint32_t i, uint32_t kChunk)
@@ -223,7 +229,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
             if ((cur & kWideLeafBit) == 0) {
                 const float4* p = P.nodes + (size_t)cur * 4;
                 const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-                const float bound = ANY ? r.tmax : fminf(tTri, F);
+                const float bound = (ANY ? r.tmax : fminf(tTri, F)) * kCullSlack;
                 float tn[4];
                 uint32_t rf[4];
                 rf[0] = __float_as_uint(q3.x); rf[1] = __float_as_uint(q3.y);

@@ -58,6 +58,12 @@ def tile_pixels(tiles, ids, width):
     return np.concatenate(parts) if parts else np.zeros(0, np.int64)
 
 
+def rank_pixels(width, height, rank, world, tile=TILE):
+    """Pixel numbers of rank `rank`'s tiles (tile i -> rank i % world), in TileTask::run's order."""
+    tiles = tile_list(width, height, tile)
+    return tile_pixels(tiles, tiles_of_rank(len(tiles), rank, world), width)
+
+
 def ray_slice(n, rank, world):
     """Batch mode: contiguous [begin, end) of an n-ray batch for `rank`; sizes differ by at most 1."""
     base, rem = divmod(n, world)
