@@ -6,8 +6,9 @@ San-Miguel-class stand-in scenes, per-iteration batch statistics and end-to-end 
     python tools/wavefront_bench.py --config c3 [--spp 64 --depth 8 --slots 4194304] [--pools] [--out file.json]
     python tools/wavefront_bench.py --config c5 --spp 256
 
-Size-independent checks at full size: the frame of a second run with another slot count (and pool mode)
-is bit-identical (a path's result does not depend on slot, batch or iteration); every pixel finite.
+Size-independent checks at full size: the frames of runs with another slot count and in pool mode are
+compared bit for bit (a path's result does not depend on slot, batch or iteration; what can still differ
+is a ray that meets two primitives at distances one ulp apart, DESIGN.md section 1: counted); every pixel finite.
 The small-size check against the CPU loop over the oracle is tests/test_wavefront_dev.py."""
 import argparse, json, os, sys, time
 import numpy as np
@@ -58,9 +59,10 @@ def main():
         wf2 = api.Wavefront(acc, max(1000, args.slots // 3 + 17))
         c, _, _ = run(args.check_spp, True, wf2)
         wf2.close()
-        out["checks"] = {"spp": args.check_spp,
-                         "regenerate_equals_pools": bool(torch.equal(a.view(torch.int32), b.view(torch.int32))),
-                         "independent_of_slot_count": bool(torch.equal(a.view(torch.int32), c.view(torch.int32))),
+        diff = lambda x, y: int((x.view(torch.int32) != y.view(torch.int32)).any(1).sum().item())
+        out["checks"] = {"spp": args.check_spp, "pixels": int(a.shape[0]),
+                         "pixels_differing_regenerate_vs_pools": diff(a, b),
+                         "pixels_differing_other_slot_count": diff(a, c),
                          "all_finite": bool(torch.isfinite(a).all().item()), "mean_rgb": [round(float(x), 5) for x in a.mean(0).tolist()]}
         del a, b, c
     for name, regen in (("regenerate", True), ("pools", False)):

@@ -46,8 +46,11 @@ struct WfBuffers {
     float4* weight;      // xyz = pathWeight (src/renderer.cpp:41), w = bounce number as int bits
     float4* color;       // xyz = colour of the sample so far (:40)
     float4* pend;        // xyz = direct-light term if the shadow ray is clear, w bits: 1 = the path goes on
-    uint32_t* counters;  // [0] next path to hand out  [1] paths finished (by a miss in the shade kernel, or in the apply kernel)  [2] closest rays this iteration  [3] shadow rays this iteration
+    uint32_t* counters;  // 4 counters, one 128-byte line each (word 32 k): [0] next path to hand out  [1] paths finished (by a miss
+                         // in the shade kernel, or in the apply kernel)  [2] closest rays this iteration  [3] shadow rays this iteration
 };
+constexpr uint32_t kCtr = 32;        // words between counters
+constexpr uint32_t kMaxBlocks = 2048;  // kernels walk the slots with a grid stride: one atomic per block and counter, not per wave
 
 struct DiffuseParams {
     float pos[3], dir[3], right[3], up[3];
@@ -84,26 +87,21 @@ __device__ inline void deadRay(float4* rays, uint32_t i)
     rays[(size_t)i * 2 + 1] = make_float4(0.57735026f, 0.57735026f, 0.57735026f, 0.0f);
 }
 
-__device__ inline void waveAdd(uint32_t* counter, bool pred)
+// adds the block's count of `n` to a counter with one atomic (call from every thread of the block)
+__device__ inline void blockAdd(uint32_t* counter, uint32_t n, uint32_t* lds)
 {
-    const uint64_t m = __ballot(pred);
-    if (m && (threadIdx.x & 63) == (uint32_t)__ffsll((long long)m) - 1u) atomicAdd(counter, (uint32_t)__popcll(m));
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o);
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0) lds[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = lds[0] + lds[1] + lds[2] + lds[3];
+        if (total) atomicAdd(counter, total);
+    }
 }
 
-__global__ void __launch_bounds__(256) wfGenerate(WfBuffers B, DiffuseParams J, uint32_t nSlots)
+__device__ inline void startPath(const WfBuffers& B, const DiffuseParams& J, uint32_t i, uint32_t p)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const bool want = i < nSlots && B.path[i] == kNoPath;
-    // one atomic per wave: its free slots take consecutive path numbers
-    const uint64_t m = __ballot(want);
-    if (m == 0) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(B.counters + 0, (uint32_t)__popcll(m));
-    base = __shfl(base, (int)leader);
-    if (!want) return;
-    const uint32_t p = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     if (p >= J.slabPaths) { deadRay(B.rays, i); return; }      // the slab's paths have all been handed out
     const uint32_t pixelIdx = p / J.slabSamples;
     const uint32_t sample = J.slabFirstSample + p % J.slabSamples;
@@ -124,13 +122,47 @@ __global__ void __launch_bounds__(256) wfGenerate(WfBuffers B, DiffuseParams J, 
     B.color[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
+// Every block owns a contiguous range of slots: it counts the free ones, reserves that many path numbers
+// with ONE atomic, and hands them to its free slots in slot order.
+__global__ void __launch_bounds__(256) wfGenerate(WfBuffers B, DiffuseParams J, uint32_t nSlots, uint32_t perBlock)
+{
+    __shared__ uint32_t lds[8];
+    const uint32_t begin = blockIdx.x * perBlock;
+    const uint32_t end = begin + perBlock < nSlots ? begin + perBlock : nSlots;
+    uint32_t mine = 0;
+    for (uint32_t i = begin + threadIdx.x; i < end; i += 256u) mine += B.path[i] == kNoPath ? 1u : 0u;
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+    if ((threadIdx.x & 63u) == 0) lds[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = lds[0] + lds[1] + lds[2] + lds[3];
+        lds[4] = total ? atomicAdd(B.counters + 0 * kCtr, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t next = lds[4];                                  // first path number of the chunk being handed out
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t c = begin; c < end; c += 256u) {
+        const uint32_t i = c + threadIdx.x;
+        const bool want = i < end && B.path[i] == kNoPath;
+        const uint64_t m = __ballot(want);
+        __syncthreads();                                     // lds[0..3] of the previous round have been read
+        if (lane == 0) lds[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+        for (uint32_t k = 0; k < 4u; ++k) { const uint32_t n = lds[k]; all += n; if (k < wave) before += n; }
+        if (want) startPath(B, J, i, next + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
+        next += all;
+    }
+}
+
 __global__ void __launch_bounds__(256) wfShade(WfBuffers B, DiffuseParams J, uint32_t nSlots, float4* slab)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const bool live = i < nSlots && B.path[i] != kNoPath;
-    waveAdd(B.counters + 2, live);
-    bool sendsShadow = false, missed = false;
+    __shared__ uint32_t lds[4];
+    uint32_t nLive = 0, nShadow = 0, nMissed = 0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < nSlots; i += gridDim.x * 256u) {
+    const bool live = B.path[i] != kNoPath;
     if (live) {
+        ++nLive;
         const uint32_t p = B.path[i];
         const float4 s0 = B.surf[(size_t)i * 3 + 0];          // normal, t
         const float4 s2 = B.surf[(size_t)i * 3 + 2];          // v, prim, meshIdx, triIdx
@@ -140,11 +172,11 @@ __global__ void __launch_bounds__(256) wfShade(WfBuffers B, DiffuseParams J, uin
             const float4 c = B.color[i];
             slab[p] = make_float4(c.x * J.invSpp, c.y * J.invSpp, c.z * J.invSpp, 0.0f);
             B.path[i] = kNoPath;
-            missed = true;
+            ++nMissed;
             deadRay(B.rays, i);
             deadRay(B.shadow, i);
         } else {
-            sendsShadow = true;
+            ++nShadow;
             const float4 o = B.rays[(size_t)i * 2 + 0], d = B.rays[(size_t)i * 2 + 1];
             float4 w = B.weight[i];
             const int bounce = __float_as_int(w.w);
@@ -211,31 +243,32 @@ __global__ void __launch_bounds__(256) wfShade(WfBuffers B, DiffuseParams J, uin
             pend.w = __int_as_float(goesOn ? 1 : 0);
             B.pend[i] = pend;
         }
-    } else if (i < nSlots) {
+    } else {
         deadRay(B.shadow, i);
     }
-    waveAdd(B.counters + 3, sendsShadow);
-    waveAdd(B.counters + 1, missed);
+    }
+    blockAdd(B.counters + 2 * kCtr, nLive, lds);
+    blockAdd(B.counters + 3 * kCtr, nShadow, lds);
+    blockAdd(B.counters + 1 * kCtr, nMissed, lds);
 }
 
 __global__ void __launch_bounds__(256) wfApply(WfBuffers B, DiffuseParams J, uint32_t nSlots, float4* slab)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    bool finished = false;
-    if (i < nSlots) {
+    __shared__ uint32_t lds[4];
+    uint32_t nFinished = 0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < nSlots; i += gridDim.x * 256u) {
         const uint32_t p = B.path[i];
-        if (p != kNoPath) {
-            const float4 pend = B.pend[i];
-            float4 c = B.color[i];
-            if (B.occ[i] == 0) { c.x = c.x + pend.x; c.y = c.y + pend.y; c.z = c.z + pend.z; }    // :104-109
-            if (__float_as_int(pend.w) == 0) {
-                slab[p] = make_float4(c.x * J.invSpp, c.y * J.invSpp, c.z * J.invSpp, 0.0f);      // :132
-                B.path[i] = kNoPath;
-                finished = true;
-            } else B.color[i] = c;
-        }
+        if (p == kNoPath) continue;
+        const float4 pend = B.pend[i];
+        float4 c = B.color[i];
+        if (B.occ[i] == 0) { c.x = c.x + pend.x; c.y = c.y + pend.y; c.z = c.z + pend.z; }    // :104-109
+        if (__float_as_int(pend.w) == 0) {
+            slab[p] = make_float4(c.x * J.invSpp, c.y * J.invSpp, c.z * J.invSpp, 0.0f);      // :132
+            B.path[i] = kNoPath;
+            ++nFinished;
+        } else B.color[i] = c;
     }
-    waveAdd(B.counters + 1, finished);
+    blockAdd(B.counters + 1 * kCtr, nFinished, lds);
 }
 
 __global__ void __launch_bounds__(256) wfReduce(const float4* slab, uint32_t nPixels, uint32_t slabSamples, float* rgb, int first)
@@ -301,7 +334,7 @@ int yart_wavefront_create(YartAccel* accel, size_t slots, YartWavefront** out)
     w->accel = accel;
     w->slots = slots;
     const size_t n = slots;
-    const size_t sizes[10] = { n * 32, n * 16, n * 48, n * 32, n, n * 4, n * 16, n * 16, n * 16, 256 };
+    const size_t sizes[10] = { n * 32, n * 16, n * 48, n * 32, n, n * 4, n * 16, n * 16, n * 16, 512 };
     size_t total = 0;
     for (size_t s : sizes) total += alignUp(s);
     hipError_t e = hipMalloc(&w->block, total);
@@ -383,7 +416,8 @@ int yart_wavefront_render_diffuse(YartWavefront* w, const YartDiffuseJob* job, f
     std::memset(&st, 0, sizeof st);
     const auto wall0 = std::chrono::steady_clock::now();
     const uint32_t nSlots = (uint32_t)w->slots;
-    const uint32_t grid = (nSlots + 255u) / 256u;
+    const uint32_t grid = std::min<uint32_t>((nSlots + 255u) / 256u, kMaxBlocks);
+    const uint32_t perBlock = ((nSlots + grid - 1u) / grid + 255u) / 256u * 256u;      // wfGenerate: contiguous slots per block
     const YartRay* dRays = reinterpret_cast<const YartRay*>(w->buf.rays);
     const YartRay* dShadow = reinterpret_cast<const YartRay*>(w->buf.shadow);
     YartHit* dHits = reinterpret_cast<YartHit*>(w->buf.hits);
@@ -397,7 +431,7 @@ int yart_wavefront_render_diffuse(YartWavefront* w, const YartDiffuseJob* job, f
         J.slabFirstSample = firstSample;
         J.slabSamples = ss;
         J.slabPaths = (uint32_t)(nPixels * ss);
-        if ((e = hipMemsetAsync(w->buf.counters, 0, 256, stream)) != hipSuccess) return hipFail(e, "hipMemsetAsync");
+        if ((e = hipMemsetAsync(w->buf.counters, 0, 512, stream)) != hipSuccess) return hipFail(e, "hipMemsetAsync");
         if ((e = hipMemsetAsync(w->buf.path, 0xFF, (size_t)nSlots * 4, stream)) != hipSuccess) return hipFail(e, "hipMemsetAsync");
         uint32_t finished = 0, handedOut = 0;
         // every iteration ends at least one bounce of every live path, and a path has at most max_depth
@@ -407,10 +441,10 @@ int yart_wavefront_render_diffuse(YartWavefront* w, const YartDiffuseJob* job, f
             const bool generate = job->regenerate ? true : (finished == handedOut);      // pool mode: only when every slot is free
             (void)hipEventRecord(w->events[0], stream);
             if (generate) {
-                hipLaunchKernelGGL(wfGenerate, dim3(grid), dim3(256), 0, stream, w->buf, J, nSlots);
+                hipLaunchKernelGGL(wfGenerate, dim3(grid), dim3(256), 0, stream, w->buf, J, nSlots, perBlock);
                 if ((e = hipGetLastError()) != hipSuccess) return hipFail(e, "wfGenerate");
             }
-            if ((e = hipMemsetAsync(w->buf.counters + 2, 0, 8, stream)) != hipSuccess) return hipFail(e, "hipMemsetAsync");
+            if ((e = hipMemsetAsync(w->buf.counters + 2 * kCtr, 0, 2 * kCtr * 4, stream)) != hipSuccess) return hipFail(e, "hipMemsetAsync");
             (void)hipEventRecord(w->events[1], stream);
             status = yart_intersect_closest_dev(w->accel, dRays, nSlots, dHits, job->flags, stream);
             if (status != YART_OK) return status;
@@ -426,9 +460,10 @@ int yart_wavefront_render_diffuse(YartWavefront* w, const YartDiffuseJob* job, f
             (void)hipEventRecord(w->events[5], stream);
             hipLaunchKernelGGL(wfApply, dim3(grid), dim3(256), 0, stream, w->buf, J, nSlots, w->slab);
             if ((e = hipGetLastError()) != hipSuccess) return hipFail(e, "wfApply");
-            uint32_t c[4];
-            if ((e = hipMemcpyAsync(c, w->buf.counters, 16, hipMemcpyDeviceToHost, stream)) != hipSuccess) return hipFail(e, "hipMemcpyAsync");
+            uint32_t raw[4 * kCtr];
+            if ((e = hipMemcpyAsync(raw, w->buf.counters, sizeof raw, hipMemcpyDeviceToHost, stream)) != hipSuccess) return hipFail(e, "hipMemcpyAsync");
             if ((e = hipStreamSynchronize(stream)) != hipSuccess) return hipFail(e, "hipStreamSynchronize");
+            const uint32_t c[4] = { raw[0], raw[kCtr], raw[2 * kCtr], raw[3 * kCtr] };
             handedOut = std::min<uint32_t>(c[0], J.slabPaths);
             const uint32_t live = c[2], senders = c[3];
             st.closest_rays += live;
