@@ -323,6 +323,37 @@ int yart_wavefront_render_diffuse(YartWavefront* wf, const YartDiffuseJob* job, 
                                   YartWavefrontStats* stats, YartWavefrontIter* iters, size_t max_iters,
                                   void* stream);
 
+/* ---- Multi-GPU image mode --------------------------------------------------------------
+ * Replaces the reference's way of spreading a frame over workers: Renderer::render cuts the image into
+ * 32x32 tiles (include/renderer.h:14, src/renderer.cpp:161-217) and 8 threads pop them from a queue
+ * (src/scheduler.cpp:46-72).  Here the scene is replicated in every GPU's HBM, tile i of the SAME list
+ * belongs to rank i % world (one process per GPU), every rank renders its tiles with no communication,
+ * and the one exchange of the path is the framebuffer gather at the end, over RCCL (xGMI inside a node).
+ * Pure index arithmetic (host, no HIP call): */
+size_t yart_tiles_count(int32_t width, int32_t height, int32_t tile);
+/* out: 4 int32 per tile = x0, y0, x1, y1 (end exclusive), in the reference's order: full tiles column
+ * by column, then the right-hand strip, the bottom strip, the corner. */
+int yart_tiles_list(int32_t width, int32_t height, int32_t tile, int32_t* out);
+/* Pixel numbers y*width+x of rank `rank`'s tiles, tile by tile, rows first (the order TileTask::run
+ * visits them, src/renderer.cpp:146-153).  out_pixels == NULL: returns the count only.  This list is
+ * what YartDiffuseJob.d_pixels takes, and the order of a rank's part in yart_frame_gather. */
+size_t yart_tiles_rank_pixels(int32_t width, int32_t height, int32_t tile, int32_t rank, int32_t world,
+                              uint32_t* out_pixels);
+
+/* Communicator over RCCL (librccl is loaded when the first communicator is made; a host without it
+ * gets YART_ERR_NO_DEVICE and keeps everything else).  Rank 0 makes the 128-byte id and hands it to the
+ * other ranks by whatever the host program has (a file, MPI, a socket); every rank then joins. */
+typedef struct YartComm YartComm;
+int yart_comm_unique_id(void* id128);
+int yart_comm_create(const void* id128, int32_t rank, int32_t world, int device, YartComm** out);
+void yart_comm_destroy(YartComm* comm);
+/* d_local_rgb: this rank's pixels, 3 floats each, in yart_tiles_rank_pixels order (device).  Rank 0
+ * receives every rank's part (one grouped ncclSend / ncclRecv exchange: a direct gather uses all inbound
+ * xGMI links of the root at once) and scatters the pixels into d_frame_rgb (width*height*3 floats,
+ * row-major, device; ignored on other ranks).  Asynchronous on `stream`; world == 1 is the local scatter. */
+int yart_frame_gather(YartComm* comm, const float* d_local_rgb, int32_t width, int32_t height, int32_t tile,
+                      float* d_frame_rgb, void* stream);
+
 /* ---- Scene ingestion -------------------------------------------------------------
  * Replaces Scene::loadFromObj(folder, file) (src/scene.cpp:159-298) and, beneath it, the bundled
  * tinyobjloader's LoadObj / LoadMtl (external/tinyobjloader/tiny_obj_loader.h:838-1133, :587-813):

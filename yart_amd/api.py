@@ -43,6 +43,8 @@ EXPORTS = [
     "yart_film_tonemap", "yart_film_write_bmp",
     "yart_accel_set_surface_data", "yart_surface_dev", "yart_surface",
     "yart_wavefront_create", "yart_wavefront_destroy", "yart_wavefront_render_diffuse",
+    "yart_tiles_count", "yart_tiles_list", "yart_tiles_rank_pixels",
+    "yart_comm_unique_id", "yart_comm_create", "yart_comm_destroy", "yart_frame_gather",
 ]
 
 
@@ -145,6 +147,16 @@ def lib():
     L.yart_wavefront_destroy.restype = None
     L.yart_wavefront_render_diffuse.argtypes = [_vp, ctypes.POINTER(DiffuseJob), _vp, ctypes.POINTER(WavefrontStats),
                                                 ctypes.POINTER(WavefrontIter), _sz, _vp]
+    L.yart_tiles_count.argtypes = [ctypes.c_int32] * 3
+    L.yart_tiles_count.restype = _sz
+    L.yart_tiles_list.argtypes = [ctypes.c_int32] * 3 + [_vp]
+    L.yart_tiles_rank_pixels.argtypes = [ctypes.c_int32] * 5 + [_vp]
+    L.yart_tiles_rank_pixels.restype = _sz
+    L.yart_comm_unique_id.argtypes = [_vp]
+    L.yart_comm_create.argtypes = [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int, ctypes.POINTER(_vp)]
+    L.yart_comm_destroy.argtypes = [_vp]
+    L.yart_comm_destroy.restype = None
+    L.yart_frame_gather.argtypes = [_vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp]
     L.yart_film_tonemap.argtypes = [_vp, _sz, _vp]
     L.yart_film_write_bmp.argtypes = [ctypes.c_char_p, _vp, ctypes.c_int32, ctypes.c_int32]
     L.yart_status_string.argtypes = [ctypes.c_int]
@@ -414,6 +426,68 @@ class Accel:
         occ = np.zeros(len(rays), np.uint8)
         _check(lib().yart_intersect_any(self._h, _p(rays), len(rays), _p(occ), flags))
         return occ
+
+
+def tiles_list(width, height, tile=32):
+    """Renderer::render's tile list (yart_tiles_list) -> int32 [n, 4] = x0, y0, x1, y1."""
+    L = lib()
+    out = np.zeros((L.yart_tiles_count(width, height, tile), 4), np.int32)
+    if len(out):
+        _check(L.yart_tiles_list(width, height, tile, _p(out)))
+    return out
+
+
+def tiles_rank_pixels(width, height, rank, world, tile=32):
+    """Pixel numbers of a rank's tiles in rendering order (yart_tiles_rank_pixels) -> uint32 [n]."""
+    L = lib()
+    n = L.yart_tiles_rank_pixels(width, height, tile, rank, world, None)
+    out = np.zeros(n, np.uint32)
+    if n:
+        got = L.yart_tiles_rank_pixels(width, height, tile, rank, world, _p(out))
+        if got != n:
+            raise YartError("yart_tiles_rank_pixels: inconsistent count")
+    return out
+
+
+class Comm:
+    """RCCL communicator for the framebuffer gather (yart_comm_*).  unique_id() on rank 0, shared by the
+    caller (torch.distributed.broadcast_object_list, a file, ...), then Comm(id, rank, world, device)."""
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(128)
+        _check(lib().yart_comm_unique_id(buf))
+        return bytes(buf.raw)
+
+    def __init__(self, unique_id, rank, world, device=0):
+        self._h = None
+        h = _vp()
+        _check(lib().yart_comm_create(ctypes.c_char_p(unique_id), rank, world, int(device), ctypes.byref(h)))
+        self._h = h
+        self.rank, self.world, self.device = rank, world, int(device)
+
+    def close(self):
+        if self._h:
+            lib().yart_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def gather_frame(self, local_rgb, width, height, tile=32, stream=None):
+        """local_rgb: float32 CUDA tensor [n_local, 3] in tiles_rank_pixels order -> [height, width, 3] on rank 0, None elsewhere."""
+        import torch
+        if not (local_rgb.is_cuda and local_rgb.is_contiguous() and local_rgb.dtype == torch.float32):
+            raise YartError("local_rgb must be a contiguous float32 CUDA tensor")
+        frame = torch.zeros((height, width, 3), dtype=torch.float32, device=local_rgb.device) if self.rank == 0 else None
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        _check(lib().yart_frame_gather(self._h, _vp(local_rgb.data_ptr()), width, height, tile,
+                                       _vp(frame.data_ptr()) if frame is not None else None, _vp(stream.cuda_stream)))
+        return frame
 
 
 class Wavefront:
