@@ -249,10 +249,63 @@ def main():
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"], out["parity_gate"]["sample_vs_cpu"] = cpu_baseline(
             verts, tris, sph, rays, a, args.cpu_seconds)
+    # ---- N > 1: the one exchange the path has (image mode), exercised once outside the timed region:
+    # every rank renders its tiles of a small frame, yart_frame_gather collects them over RCCL, rank 0 compares
+    # with its own unsharded render.  Guarded by a watchdog: a stuck collective must not cost the bench line.
+    stuck = False
+    if world > 1 and own_gpu and os.environ.get("YART_BENCH_SKIP_GATHER_CHECK") != "1":
+        import threading
+        box = {}
+        th = threading.Thread(target=lambda: box.update(gather_check(rank, world, device)), daemon=True)
+        th.start()
+        th.join(180.0)
+        stuck = th.is_alive()
+        out["multi_gpu_gather_check"] = {"error": "timed out after 180 s"} if stuck else box
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if stuck:
+        os._exit(0)
     if world > 1:
         dist.destroy_process_group()
+
+
+def gather_check(rank, world, device):
+    """Tile-sharded render of a small frame + yart_frame_gather over an RCCL communicator of the C-ABI;
+    -> dict for the JSON line (rank 0's view)."""
+    import torch
+    import torch.distributed as dist
+    from yart_amd import api, scenes
+    from oracle import diffuse_ref as dr          # camera_basis only: host arithmetic of Camera::Camera
+    try:
+        W, H = 640, 360
+        v, t, s = scenes.architectural(40000, seed=2)
+        acc = api.Accel(v, t, s, device=device)
+        acc.set_surface_data(v, t, np.zeros_like(v), s)
+        cam = dr.camera_basis([-10.0, 5.0, 0.0], [1.0, -0.1, 0.05], W, H, 0.785398)
+        job = (cam, W, H, 2, 4, [0.0, 9.0, 0.0], [60.0, 55.0, 50.0], [0.5, 0.5, 0.5])
+        wf = api.Wavefront(acc, 1 << 16)
+        ids = [api.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        comm = api.Comm(ids[0], rank, world, device=device)
+        pix = torch.from_numpy(api.tiles_rank_pixels(W, H, rank, world).astype(np.int32)).cuda()
+        local, _, _ = wf.render_diffuse(*job, seed=5, pixels=pix)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        frame = comm.gather_frame(local, W, H)
+        torch.cuda.synchronize()
+        dist.barrier()
+        ms = (time.perf_counter() - t0) * 1e3
+        res = {"ranks": world, "frame": "%dx%d" % (W, H), "gather_ms_incl_barrier": round(ms, 3)}
+        if rank == 0:
+            full, _, _ = wf.render_diffuse(*job, seed=5)
+            res["rccl_gathered_frame_equals_single_rank_render_bitwise"] = bool(
+                torch.equal(full.view(H, W, 3).view(torch.int32), frame.view(torch.int32)))
+        comm.close()
+        wf.close()
+        acc.close()
+        return res
+    except Exception as exc:                       # reported, never fatal to the bench line
+        return {"error": repr(exc)}
 
 
 def cpu_baseline(verts, tris, sph, rays, gpu_hits, budget_s):

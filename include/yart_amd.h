@@ -201,6 +201,12 @@ size_t yart_accel_num_wide_nodes(const YartAccel* accel);
 size_t yart_accel_num_wide_prims(const YartAccel* accel);
 int yart_accel_wide_depth(const YartAccel* accel);
 int yart_accel_get_wide(const YartAccel* accel, void* nodes_out, void* rows_a_out, void* rows_bc_out);
+/* 1 if the 4-wide tree of this accel was built on the GPU (environment YART_BUILD_DEVICE=1 at create:
+ * Morton-ordered linear BVH, collapse plan, quantised nodes and leaf rows by kernels, while the host
+ * builds the reference's tree; no counterpart in the reference, whose build is src/bvhaccel.cpp:100-151),
+ * 0 if the host builder made it (the default: binned SAH, better trees, seconds for 10^7 primitives).
+ * ms_out (optional): wall milliseconds of the device build. */
+int yart_accel_wide_built_on_device(const YartAccel* accel, double* ms_out);
 /* Depth of the triangle tree (root = 1) and bytes resident in HBM. */
 int yart_accel_depth(const YartAccel* accel);
 size_t yart_accel_device_bytes(const YartAccel* accel);

@@ -50,6 +50,11 @@ def prim_boxes(g, rows_a, rows_bc):
 def test_structure(golden, max_leaf):
     g = golden
     nodes, rows_a, rows_bc, depth = api.build_wide_host(g["verts"], g["tris"], g["spheres"], max_leaf)
+    check_structure(g, nodes, rows_a, rows_bc, depth, max_leaf)
+
+
+def check_structure(g, nodes, rows_a, rows_bc, depth, max_leaf):
+    """Shared with tests/test_device_build.py (the tree the GPU builds must pass the same checks)."""
     assert 3 * depth + 1 <= 64 and len(rows_a) == len(g["tris"]) + len(g["spheres"])
     ta, tri_box = prim_boxes(g, rows_a, rows_bc)
     lo, hi, refs = decode(nodes)

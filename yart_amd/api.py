@@ -37,7 +37,7 @@ EXPORTS = [
     "yart_accel_get_nodes", "yart_accel_get_triaccel", "yart_accel_depth",
     "yart_accel_device_bytes", "yart_build_host", "yart_status_string", "yart_last_error",
     "yart_accel_profile_enable", "yart_accel_profile_read",
-    "yart_build_wide_host", "yart_accel_num_wide_nodes", "yart_accel_num_wide_prims", "yart_accel_wide_depth", "yart_accel_get_wide",
+    "yart_build_wide_host", "yart_accel_num_wide_nodes", "yart_accel_num_wide_prims", "yart_accel_wide_depth", "yart_accel_get_wide", "yart_accel_wide_built_on_device",
     "yart_obj_load", "yart_obj_free", "yart_obj_num_meshes", "yart_obj_num_vertices", "yart_obj_num_triangles",
     "yart_obj_num_materials", "yart_obj_num_spheres", "yart_obj_get", "yart_obj_mesh_name", "yart_obj_material_name",
     "yart_film_tonemap", "yart_film_write_bmp",
@@ -119,6 +119,7 @@ def lib():
         getattr(L, name).restype = _sz
     L.yart_accel_depth.argtypes = [_vp]
     L.yart_accel_wide_depth.argtypes = [_vp]
+    L.yart_accel_wide_built_on_device.argtypes = [_vp, ctypes.POINTER(ctypes.c_double)]
     L.yart_accel_get_wide.argtypes = [_vp, _vp, _vp, _vp]
     L.yart_accel_get_nodes.argtypes = [_vp, _vp]
     L.yart_accel_get_triaccel.argtypes = [_vp, _vp]
@@ -309,6 +310,12 @@ class Accel:
     @property
     def wide_depth(self):
         return lib().yart_accel_wide_depth(self._h)
+
+    @property
+    def wide_built_on_device(self):
+        """-> (bool, milliseconds) : whether the GPU built the 4-wide tree (YART_BUILD_DEVICE=1) and how long it took."""
+        ms = ctypes.c_double()
+        return bool(lib().yart_accel_wide_built_on_device(self._h, ctypes.byref(ms))), ms.value
 
     def wide(self):
         """-> (nodes uint32 [nNodes, 16], rowsA float32 [nPrims, 4], rowsBC float32 [nPrims, 8]) of the

@@ -32,6 +32,8 @@ struct YartAccel {
     void* dSurfRows = nullptr;        // hit post-processing (yart_accel_set_surface_data)
     void* dSurfSpheres = nullptr;
     bool hasWide = false;
+    bool wideBuiltOnDevice = false;    // YART_BUILD_DEVICE=1 and the device builder took the scene
+    double msWideDeviceBuild = 0.0;
     bool wideMergedRows = false;       // rowsA | rowsBC of a primitive in one 64-byte record (dWideRowsA), dWideRowsBC unused
     size_t wideNodes = 0, widePrims = 0;   // array sizes; the device copy is the only one kept
     int wideDepth = 0;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -12,6 +13,7 @@
 #include <new>
 #include <memory>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -20,6 +22,7 @@
 #include "accel.h"
 #include "traverse.h"
 #include "wide_build.h"
+#include "wide_build_dev.h"
 #include "obj_ingest.h"
 #include "task_pool.h"
 
@@ -294,13 +297,31 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
     if (a->wideChunk < 64) a->wideChunk = 64;
     if (a->wideChunk > 4096) a->wideChunk = 4096;
     std::string err;
+    const char* noWide = std::getenv("YART_NO_WIDE");
+    const bool wantWide = !(noWide && noWide[0] == '1');
+    // YART_BUILD_DEVICE=1: the 4-wide tree is built on the GPU (wide_build_dev.hip).  Its first phase needs only
+    // the scene and runs in a thread of its own while this one builds the reference's tree.
+    const char* devBuild = std::getenv("YART_BUILD_DEVICE");
+    const bool wantDeviceBuild = wantWide && devBuild && devBuild[0] == '1' && n_tris + n_spheres >= 2;
+    const auto tBuild0 = std::chrono::steady_clock::now();
+    yart::DeviceWideBuilder devBuilder;
+    std::thread devThread;
+    int devStatus = YART_ERR_HIP;
+    std::string devErr;
+    if (wantDeviceBuild) {
+        devThread = std::thread([&]() {
+            if (hipSetDevice(device) != hipSuccess) { devErr = "hipSetDevice failed"; return; }
+            devStatus = devBuilder.topology(verts, n_verts, tris, n_tris, spheres, n_spheres, devErr);
+        });
+    }
     int st = yart::buildTriangleBvh(verts, n_verts, tris, n_tris, a->tri, err);
     yart::SphereBvh sph;
     if (st == YART_OK) st = yart::buildSphereBvh(spheres, n_spheres, sph, err);
+    if (devThread.joinable()) devThread.join();
+    const double msRefTree = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tBuild0).count();
+    const bool useDeviceBuild = wantDeviceBuild && devStatus == YART_OK;
     yart::WideBvh wide;
-    const char* noWide = std::getenv("YART_NO_WIDE");
-    const bool wantWide = !(noWide && noWide[0] == '1');
-    if (st == YART_OK && wantWide) {
+    if (st == YART_OK && wantWide && !useDeviceBuild) {
         int maxLeaf = 1;            // measured best on MI355X (tools/exp_wide.py): the box of a single primitive is a
                                     // cheaper rejection than its plane row, and rows of different leaves are not tested
         if (const char* v = std::getenv("YART_WIDE_LEAF")) maxLeaf = std::atoi(v);
@@ -334,7 +355,23 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
     if (st == YART_OK) st = upload(&a->dSphPairs, sph.pairs.data(), sph.pairs.size() * sizeof(yart::DevNodePair), a->deviceBytes);
     if (st == YART_OK) st = upload(&a->dSphRecs, sph.records.data(), sph.records.size() * sizeof(float), a->deviceBytes);
     if (st == YART_OK) st = upload(&a->dSphIndex, sph.index.data(), sph.index.size() * sizeof(uint32_t), a->deviceBytes);
-    if (st == YART_OK && wantWide) {
+    if (st == YART_OK && useDeviceBuild) {
+        // second phase of the device build: leaf rows from the reference's TriAccel records and leaf order
+        yart::DeviceWide dw;
+        st = devBuilder.finish(a->dTriAccel, a->tri.slotOfInput.data(), dw, err);
+        if (st != YART_OK) st = fail(st, err);
+        else {
+            a->dWideNodes = dw.nodes; a->dWideRowsA = dw.rowsA; a->dWideRowsBC = dw.rowsBC;
+            a->wideNodes = dw.numNodes; a->widePrims = dw.numPrims; a->wideDepth = dw.depth;
+            a->deviceBytes += dw.numNodes * sizeof(yart::WideNode) + dw.numPrims * 48;
+            a->hasWide = true;
+            a->wideBuiltOnDevice = true;
+            a->msWideDeviceBuild = dw.msBuild;
+            if (std::getenv("YART_BUILD_TIMING"))
+                fprintf(stderr, "device wide build: %.1f ms from start to leaf rows (%zu nodes, depth %d); reference tree on the host meanwhile: %.1f ms\n",
+                        dw.msBuild, dw.numNodes, dw.depth, msRefTree);
+        }
+    } else if (st == YART_OK && wantWide) {
         st = upload(&a->dWideNodes, wide.nodes.data(), wide.nodes.size() * sizeof(yart::WideNode), a->deviceBytes);
         const char* merged = std::getenv("YART_WIDE_MERGED_ROWS");
         a->wideMergedRows = merged && merged[0] == '1';
@@ -541,6 +578,11 @@ int yart_accel_get_triaccel(const YartAccel* a, YartTriAccel* out)
 size_t yart_accel_num_wide_nodes(const YartAccel* a) { return a ? a->wideNodes : 0; }
 size_t yart_accel_num_wide_prims(const YartAccel* a) { return a ? a->widePrims : 0; }
 int yart_accel_wide_depth(const YartAccel* a) { return a ? a->wideDepth : 0; }
+int yart_accel_wide_built_on_device(const YartAccel* a, double* ms_out)
+{
+    if (ms_out) *ms_out = a ? a->msWideDeviceBuild : 0.0;
+    return a && a->wideBuiltOnDevice ? 1 : 0;
+}
 
 int yart_accel_get_wide(const YartAccel* a, void* nodes_out, void* rows_a_out, void* rows_bc_out)
 {

@@ -48,6 +48,7 @@ struct Box {
 struct BPrim {
     float lo[3], hi[3], c[3];
     uint32_t id;                // input triangle number, or kSphereId | sphere number
+    uint64_t code;              // Morton code of the centre (YART_WIDE_BUILDER=lbvh only)
 };
 
 struct BNode {                          // trivially constructible: the pool below is never value-initialised
@@ -80,9 +81,57 @@ public:
         nodes_[0] = BNode{};
     }
 
+    // YART_WIDE_BUILDER=lbvh: the topology of a linear BVH (primitives in Morton order of their centres, every
+    // range cut where the highest differing code bit flips) instead of binned SAH -- what the device builder
+    // (wide_build_dev.hip) produces; kept on the host to compare tree quality without a GPU.
+    void sortMorton()
+    {
+        Box cb;
+        cb.reset();
+        for (const BPrim& p : prims_) cb.grow(p.c, p.c);
+        float inv[3];
+        for (int a = 0; a < 3; ++a) {
+            const float e = cb.hi[a] - cb.lo[a];
+            inv[a] = (e > 0.0f && e < std::numeric_limits<float>::infinity()) ? 2097151.0f / e : 0.0f;
+        }
+        auto spread = [](uint64_t v) {
+            v &= 0x1FFFFFull;
+            v = (v | (v << 32)) & 0x1F00000000FFFFull;
+            v = (v | (v << 16)) & 0x1F0000FF0000FFull;
+            v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+            v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+            v = (v | (v << 2)) & 0x1249249249249249ull;
+            return v;
+        };
+        for (BPrim& p : prims_) {
+            uint64_t q[3];
+            for (int a = 0; a < 3; ++a) {
+                float f = (p.c[a] - cb.lo[a]) * inv[a];
+                f = f < 0.0f ? 0.0f : (f > 2097151.0f ? 2097151.0f : f);
+                q[a] = static_cast<uint64_t>(f);
+            }
+            p.code = spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2);
+        }
+        std::sort(prims_.begin(), prims_.end(), [](const BPrim& a, const BPrim& b) { return a.code < b.code || (a.code == b.code && a.id < b.id); });
+    }
+
+    uint32_t lbvhSplit(uint32_t begin, uint32_t end) const
+    {
+        const uint64_t first = prims_[begin].code, last = prims_[end - 1].code;
+        if (first == last) return begin + (end - begin) / 2;
+        const int bit = 63 - __builtin_clzll(first ^ last);          // highest bit in which the range's codes differ
+        uint32_t lo = begin, hi = end - 1;                            // first index whose code has that bit set
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if ((prims_[mid].code >> bit) & 1ull) hi = mid; else lo = mid;
+        }
+        return hi;
+    }
+
     void run()
     {
         next_ = 1;
+        if (lbvh_) sortMorton();
         unsigned nThreads = buildThreads();
         if (prims_.size() < kSpawnAbove) nThreads = 1;
         pool_.run(nThreads, Job{ 0u, 0u, static_cast<uint32_t>(prims_.size()) },
@@ -204,6 +253,7 @@ private:
         if (!(ext[widest] > 0.0f) || !(ext[widest] < std::numeric_limits<float>::infinity()))
             return begin + count / 2;                    // all centroids coincide (or are not finite)
         if (medianOnly_) return median(begin, end, widest);
+        if (lbvh_) return lbvhSplit(begin, end);
 
         const int nBins = count > static_cast<uint32_t>(fineBinsBelow_) ? bins_ : fineBins_;
         int bestAxis = -1, bestSplit = 0;
@@ -260,6 +310,7 @@ private:
     std::atomic<uint32_t> next_{ 1 };
     int maxLeaf_;
     bool medianOnly_;
+    bool lbvh_ = [] { const char* v = std::getenv("YART_WIDE_BUILDER"); return v && std::string(v) == "lbvh"; }();
     // SAH binning: bins per axis, all three axes below oneAxisAbove_ primitives (the widest only above)
     int bins_ = std::max(2, std::min(kMaxBins, envInt("YART_SAH_BINS", 16)));
     int fineBins_ = std::max(2, std::min(kMaxBins, envInt("YART_SAH_FINE_BINS", 16)));

@@ -1,0 +1,38 @@
+// The 4-wide tree of wide_build.h built on the GPU (wide_build_dev.hip).  Two phases, so that the
+// first -- everything that needs only the scene -- can run while the host still builds the reference's
+// tree, whose leaf order (the primitive ids of YartHit) the leaf rows of the second phase carry.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+namespace yart {
+
+struct DeviceWide {
+    void* nodes = nullptr;          // device arrays, owned by the caller after finish(): hipFree
+    void* rowsA = nullptr;
+    void* rowsBC = nullptr;
+    size_t numNodes = 0, numPrims = 0;
+    int depth = 0;
+    double msBuild = 0.0;           // wall time from topology() to the end of finish()
+};
+
+class DeviceWideBuilder {
+public:
+    DeviceWideBuilder();
+    ~DeviceWideBuilder();
+    DeviceWideBuilder(const DeviceWideBuilder&) = delete;
+    DeviceWideBuilder& operator=(const DeviceWideBuilder&) = delete;
+    // Host arrays as yart_accel_create takes them; the accel's device must be current in the calling thread.
+    // YART_ERR_TREE_TOO_DEEP: the linear BVH of this scene does not fit the traversal stack (use the host builder).
+    int topology(const float* verts, size_t nVerts, const int32_t* tris, size_t nTris, const float* spheres, size_t nSpheres,
+                 std::string& err);
+    // dTriAccel: the reference's TriAccel records in leaf order on the device; slotOfInput: host, leaf slot per input triangle.
+    int finish(const void* dTriAccel, const uint32_t* slotOfInput, DeviceWide& out, std::string& err);
+
+private:
+    struct State;
+    State* state_ = nullptr;
+};
+
+} // namespace yart

@@ -1,0 +1,598 @@
+// wide_build_dev.hip -- the engine's 4-wide tree (wide_build.h) built ON THE GPU.
+//
+// The reference builds its tree on one host thread (src/bvhaccel.cpp:100-151, :309-363); the library's
+// host builder (wide_build.cpp, binned SAH on a thread pool) needs 3 s for the 11 M primitives of BASELINE
+// configs[3].  Here the same arrays -- 64-byte quantised nodes, first- and second-stage leaf rows, one
+// primitive per leaf -- come out of a chain of data-parallel kernels in tens of milliseconds:
+//
+//   primBoxes   box + centre per primitive (triangles from the vertices, spheres widened as on the host)
+//   codes       63-bit Morton code of the centre inside the bounds of all centres; radix sort (hipcub)
+//   hierarchy   the linear-BVH topology over the sorted codes: every internal node finds its range and
+//               split from code prefixes alone (Karras 2012), no dependence between nodes
+//   levels      depth of every node, top-down, one launch per level
+//   fit + plan  boxes bottom-up and, with them, the collapse plan of wide_build.cpp (least summed area
+//               of the wide nodes, a dynamic programme over (node, slots)), one launch per level: a
+//               kernel boundary is the only ordering between a node and its children
+//   emit        wide nodes top-down, one launch per wide level, children numbered by one atomic per wave
+//   rows        leaf rows in Morton order of the primitives (neighbours in space = neighbours in memory)
+//
+// Tree quality: spatial-median splits instead of binned SAH: +6 % node visits per ray on the uniform soup,
+// +9..17 % on the architectural stand-in (tools/tree_quality.py, YART_WIDE_BUILDER=lbvh is the same
+// topology built on the host).  The traversal kernel, the node format and every primitive test are the
+// same, so results are identical to the host-built tree's up to exact-t ties.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <chrono>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/yart_amd.h"
+#include "wide_build.h"
+#include "wide_build_dev.h"
+
+namespace yart {
+namespace {
+
+constexpr uint32_t kNoParent = 0xFFFFFFFFu;
+
+#define YART_HIP(call)                                                                              \
+    do {                                                                                            \
+        const hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e_); return YART_ERR_HIP; } \
+    } while (0)
+
+struct Plan { float cost[4]; uint8_t take[4]; };
+
+__device__ inline uint32_t orderedBits(float f)           // monotone float -> uint
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float fromOrdered(uint32_t k)
+{
+    const uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// bounds[0..2] = min of centres (ordered bits), [3..5] = max, [6] = valid primitives
+__global__ void __launch_bounds__(256) primBoxes(const float* __restrict__ verts, const int32_t* __restrict__ tris, uint32_t nTris,
+                                                 const float* __restrict__ spheres, uint32_t nSpheres, uint32_t nVerts,
+                                                 float4* __restrict__ lo, float4* __restrict__ hi, uint32_t* __restrict__ bounds)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t n = nTris + nSpheres;
+    float l[3] = { 0, 0, 0 }, h[3] = { 0, 0, 0 };
+    bool valid = false;
+    if (i < nTris) {
+        const int32_t* t = tris + (size_t)i * 5;
+        valid = true;
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t vi = (uint32_t)t[k];
+            if (vi >= nVerts) { valid = false; break; }          // cannot happen: the reference-tree build rejected it
+            const float* v = verts + (size_t)vi * 3;
+            for (int a = 0; a < 3; ++a) {
+                l[a] = k == 0 ? v[a] : fminf(l[a], v[a]);
+                h[a] = k == 0 ? v[a] : fmaxf(h[a], v[a]);
+            }
+        }
+        // fminf / fmaxf drop a NaN operand where std::min / std::max keep the first: test the vertices themselves
+        if (valid)
+            for (int k = 0; k < 3; ++k) {
+                const float* v = verts + (size_t)(uint32_t)t[k] * 3;
+                if (!(v[0] == v[0] && v[1] == v[1] && v[2] == v[2])) valid = false;
+            }
+    } else if (i < n) {
+        const float* s = spheres + (size_t)(i - nTris) * 4;
+        const float r = fabsf(s[3]);
+        for (int a = 0; a < 3; ++a) {
+            const float margin = 1e-5f * (fabsf(s[a]) + r) + 1e-30f;          // as wide_build.cpp
+            l[a] = s[a] - r - margin;
+            h[a] = s[a] + r + margin;
+        }
+        valid = true;
+    }
+    if (valid) for (int a = 0; a < 3; ++a) if (!(l[a] <= h[a])) valid = false;      // NaN: can never be hit, left out
+    if (i < n) {
+        lo[i] = make_float4(l[0], l[1], l[2], valid ? 1.0f : 0.0f);
+        hi[i] = make_float4(h[0], h[1], h[2], 0.0f);
+    }
+    // centre bounds: wave reduction, one atomic per wave and component
+    for (int a = 0; a < 3; ++a) {
+        const float c = 0.5f * l[a] + 0.5f * h[a];
+        uint32_t mn = valid ? orderedBits(c) : 0xFFFFFFFFu, mx = valid ? orderedBits(c) : 0u;
+        for (int o = 32; o > 0; o >>= 1) {
+            mn = min(mn, (uint32_t)__shfl_down(mn, o));
+            mx = max(mx, (uint32_t)__shfl_down(mx, o));
+        }
+        if ((threadIdx.x & 63u) == 0) { atomicMin(bounds + a, mn); atomicMax(bounds + 3 + a, mx); }
+    }
+    const uint64_t m = __ballot(valid);
+    if ((threadIdx.x & 63u) == 0 && m) atomicAdd(bounds + 6, (uint32_t)__popcll(m));
+}
+
+__device__ inline uint64_t spread21(uint64_t v)
+{
+    v &= 0x1FFFFFull;
+    v = (v | (v << 32)) & 0x1F00000000FFFFull;
+    v = (v | (v << 16)) & 0x1F0000FF0000FFull;
+    v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+    v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+
+__global__ void __launch_bounds__(256) mortonCodes(const float4* __restrict__ lo, const float4* __restrict__ hi, uint32_t n,
+                                                   const uint32_t* __restrict__ bounds, uint64_t* __restrict__ codes, uint32_t* __restrict__ ids)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 l = lo[i], h = hi[i];
+    ids[i] = i;
+    if (l.w == 0.0f) { codes[i] = ~0ull; return; }          // invalid primitives sort to the end
+    const float c[3] = { 0.5f * l.x + 0.5f * h.x, 0.5f * l.y + 0.5f * h.y, 0.5f * l.z + 0.5f * h.z };
+    uint64_t q[3];
+    for (int a = 0; a < 3; ++a) {
+        const float mn = fromOrdered(bounds[a]), mx = fromOrdered(bounds[3 + a]);
+        const float e = mx - mn;
+        const float inv = (e > 0.0f && e < __builtin_inff()) ? 2097151.0f / e : 0.0f;
+        float f = (c[a] - mn) * inv;
+        f = f < 0.0f ? 0.0f : (f > 2097151.0f ? 2097151.0f : f);
+        q[a] = (uint64_t)f;
+    }
+    codes[i] = spread21(q[0]) | (spread21(q[1]) << 1) | (spread21(q[2]) << 2);
+}
+
+// length of the common prefix of the keys (code, position) of sorted positions i and j; -1 outside the array
+__device__ inline int prefix(const uint64_t* codes, int n, int i, int j)
+{
+    if (j < 0 || j >= n) return -1;
+    const uint64_t a = codes[i], b = codes[j];
+    if (a != b) return __clzll((long long)(a ^ b));
+    return 64 + __clz(i ^ j);
+}
+
+// Internal node i of n - 1; leaf j is node (n - 1) + j.  left/right: child node numbers.
+__global__ void __launch_bounds__(256) hierarchy(const uint64_t* __restrict__ codes, int n, uint32_t* __restrict__ left,
+                                                 uint32_t* __restrict__ right, uint32_t* __restrict__ parent)
+{
+    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (i >= n - 1) return;
+    const int d = prefix(codes, n, i, i + 1) - prefix(codes, n, i, i - 1) > 0 ? 1 : -1;
+    const int dMin = prefix(codes, n, i, i - d);
+    int lMax = 2;
+    while (prefix(codes, n, i, i + lMax * d) > dMin) lMax *= 2;
+    int l = 0;
+    for (int t = lMax / 2; t >= 1; t /= 2)
+        if (prefix(codes, n, i, i + (l + t) * d) > dMin) l += t;
+    const int j = i + l * d;
+    const int dNode = prefix(codes, n, i, j);
+    int s = 0;
+    for (int t = (l + 1) / 2;; t = (t + 1) / 2) {
+        if (t < 1) break;
+        if (prefix(codes, n, i, i + (s + t) * d) > dNode) s += t;
+        if (t == 1) break;
+    }
+    const int gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int first = i < j ? i : j, last = i < j ? j : i;
+    const uint32_t lc = (first == gamma) ? (uint32_t)(n - 1 + gamma) : (uint32_t)gamma;
+    const uint32_t rc = (last == gamma + 1) ? (uint32_t)(n - 1 + gamma + 1) : (uint32_t)(gamma + 1);
+    left[i] = lc;
+    right[i] = rc;
+    parent[lc] = (uint32_t)i;
+    parent[rc] = (uint32_t)i;
+    if (i == 0) parent[0] = kNoParent;
+}
+
+// depth of the children of every internal node at depth `level`; *any = 1 if there was such a node
+__global__ void __launch_bounds__(256) assignLevel(const uint32_t* __restrict__ left, const uint32_t* __restrict__ right, uint32_t nInternal,
+                                                   uint32_t* __restrict__ depth, uint32_t level, uint32_t* __restrict__ any)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nInternal || depth[i] != level) return;
+    depth[left[i]] = level + 1;
+    depth[right[i]] = level + 1;
+    *any = 1u;
+}
+
+__device__ inline float halfArea(const float4& l, const float4& h)
+{
+    const float dx = h.x - l.x, dy = h.y - l.y, dz = h.z - l.z;
+    if (!(dx >= 0.0f && dy >= 0.0f && dz >= 0.0f)) return 0.0f;
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// leaves: node box = box of the primitive at that sorted position, plan = none (wide_build.cpp planNode)
+__global__ void __launch_bounds__(256) leafNodes(const float4* __restrict__ primLo, const float4* __restrict__ primHi,
+                                                 const uint32_t* __restrict__ sortedIds, uint32_t n, float4* __restrict__ nodeLo,
+                                                 float4* __restrict__ nodeHi, Plan* __restrict__ plan)
+{
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t node = n - 1 + j, p = sortedIds[j];
+    nodeLo[node] = primLo[p];
+    nodeHi[node] = primHi[p];
+    Plan pl;
+    for (int k = 0; k < 4; ++k) { pl.cost[k] = 0.0f; pl.take[k] = 0; }
+    plan[node] = pl;
+}
+
+// internal nodes of one level: box = union of the children's, collapse plan from theirs (wide_build.cpp planNode)
+__global__ void __launch_bounds__(256) fitLevel(const uint32_t* __restrict__ left, const uint32_t* __restrict__ right, uint32_t nInternal,
+                                                const uint32_t* __restrict__ depth, uint32_t level, float4* __restrict__ nodeLo,
+                                                float4* __restrict__ nodeHi, Plan* __restrict__ plan)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nInternal || depth[i] != level) return;
+    const uint32_t a = left[i], b = right[i];
+    const float4 al = nodeLo[a], ah = nodeHi[a], bl = nodeLo[b], bh = nodeHi[b];
+    const float4 l = make_float4(fminf(al.x, bl.x), fminf(al.y, bl.y), fminf(al.z, bl.z), 1.0f);
+    const float4 h = make_float4(fmaxf(ah.x, bh.x), fmaxf(ah.y, bh.y), fmaxf(ah.z, bh.z), 0.0f);
+    nodeLo[i] = l;
+    nodeHi[i] = h;
+    const Plan pa = plan[a], pb = plan[b];
+    float forest[5];
+    uint8_t split[5];
+    for (int k = 2; k <= 4; ++k) {
+        forest[k] = __builtin_inff();
+        split[k] = 1;
+        for (int j = 1; j < k; ++j) {
+            const float c = pa.cost[j - 1] + pb.cost[k - j - 1];
+            if (c < forest[k]) { forest[k] = c; split[k] = (uint8_t)j; }
+        }
+    }
+    Plan p;
+    const float asNode = halfArea(l, h) + forest[4];
+    p.cost[0] = asNode;
+    p.take[0] = split[4];
+    for (int k = 2; k <= 4; ++k) {
+        if (forest[k] < asNode) { p.cost[k - 1] = forest[k]; p.take[k - 1] = split[k]; }
+        else { p.cost[k - 1] = asNode; p.take[k - 1] = 0; }
+    }
+    plan[i] = p;
+}
+
+struct QueueEntry { uint32_t bnode, wide; };
+
+// the binary nodes that fill `slots` slots of a parent for the subtree at b (wide_build.cpp gather), iteratively
+__device__ inline void gatherKids(const uint32_t* left, const uint32_t* right, const Plan* plan, uint32_t nInternal,
+                                  uint32_t b, int slots, uint32_t* kids, int& n)
+{
+    uint32_t stackNode[4];
+    int stackSlots[4];
+    int sp = 0;
+    stackNode[0] = b; stackSlots[0] = slots; sp = 1;
+    while (sp > 0) {
+        --sp;
+        const uint32_t x = stackNode[sp];
+        const int s = stackSlots[sp];
+        const bool leaf = x >= nInternal;
+        const uint8_t tk = (leaf || s == 1) ? 0 : plan[x].take[s - 1];
+        if (leaf || s == 1 || tk == 0) { kids[n++] = x; continue; }
+        // right part first onto the stack so that the left part is emitted first
+        stackNode[sp] = right[x]; stackSlots[sp] = s - tk; ++sp;
+        stackNode[sp] = left[x]; stackSlots[sp] = tk; ++sp;
+    }
+}
+
+// Quantise up to four child boxes on the grid of their union (wide_build.cpp setChildren): containment is
+// decided in double on the float values the traversal kernel will read.
+__device__ inline void setChildren(WideNode& w, const float4* lo, const float4* hi, const uint32_t* refs, int n)
+{
+    for (int a = 0; a < 3; ++a) {
+        w.origin[a] = 0.0f;
+        w.scale[a] = 1.0f;
+        for (int c = 0; c < 4; ++c) { w.qlo[a][c] = 255; w.qhi[a][c] = 0; }
+    }
+    for (int c = 0; c < 4; ++c) w.ref[c] = kWideNone;
+    float cl[4][3], ch[4][3];
+    for (int i = 0; i < n; ++i) {
+        const float l3[3] = { lo[i].x, lo[i].y, lo[i].z }, h3[3] = { hi[i].x, hi[i].y, hi[i].z };
+        for (int a = 0; a < 3; ++a) {                     // keep the grid arithmetic finite
+            cl[i][a] = fmaxf(l3[a], -8.0e37f);
+            ch[i][a] = fminf(h3[a], 8.0e37f);
+        }
+    }
+    for (int a = 0; a < 3; ++a) {
+        float allLo = __builtin_inff(), allHi = -__builtin_inff();
+        for (int i = 0; i < n; ++i) { allLo = fminf(allLo, cl[i][a]); allHi = fmaxf(allHi, ch[i][a]); }
+        const float origin = allLo;
+        float scale = (allHi - allLo) / 255.0f;
+        if (!(scale > 0.0f) || !(scale < __builtin_inff())) scale = 1.0f;      // flat or unbounded axis
+        for (int guard = 0; guard < 64; ++guard) {
+            bool ok = true;
+            for (int i = 0; i < n && ok; ++i) {
+                const double l = cl[i][a], h = ch[i][a];
+                double ql = floor((l - (double)origin) / (double)scale), qh = ceil((h - (double)origin) / (double)scale);
+                while (ql > 0.0 && (double)origin + ql * (double)scale > l) ql -= 1.0;
+                while ((double)origin + qh * (double)scale < h) qh += 1.0;
+                if (ql < 0.0) ql = 0.0;
+                if (qh > 255.0) { ok = false; break; }
+                w.qlo[a][i] = (uint8_t)ql;
+                w.qhi[a][i] = (uint8_t)qh;
+            }
+            if (ok) break;
+            scale = nextafterf(scale * 1.000001f, __builtin_inff());
+        }
+        w.origin[a] = origin;
+        w.scale[a] = scale;
+    }
+    for (int i = 0; i < n; ++i) w.ref[i] = refs[i];
+}
+
+// One wide level: every queue entry becomes a wide node; its interior children get node numbers (one atomic
+// per wave) and go onto the next level's queue.
+__global__ void __launch_bounds__(256) emitLevel(const QueueEntry* __restrict__ queue, uint32_t nQueue, QueueEntry* __restrict__ nextQueue,
+                                                 uint32_t* __restrict__ counters /* [0] wide nodes so far, [1] next queue length */,
+                                                 const uint32_t* __restrict__ left, const uint32_t* __restrict__ right, const Plan* __restrict__ plan,
+                                                 uint32_t nInternal, uint32_t nTris, const uint32_t* __restrict__ sortedIds,
+                                                 const float4* __restrict__ nodeLo, const float4* __restrict__ nodeHi, WideNode* __restrict__ out)
+{
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    const bool active = q < nQueue;
+    uint32_t kids[4];
+    int n = 0;
+    QueueEntry e{ 0, 0 };
+    if (active) {
+        e = queue[q];
+        const int leftSlots = plan[e.bnode].take[0];
+        gatherKids(left, right, plan, nInternal, left[e.bnode], leftSlots, kids, n);
+        gatherKids(left, right, plan, nInternal, right[e.bnode], 4 - leftSlots, kids, n);
+    }
+    uint32_t nInterior = 0;
+    for (int i = 0; i < n; ++i) nInterior += kids[i] < nInternal ? 1u : 0u;
+    // wave prefix sum of nInterior -> node numbers and queue slots with one atomic pair per wave
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t incl = nInterior;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if (lane >= (uint32_t)o) incl += v;
+    }
+    const uint32_t total = __shfl(incl, 63);
+    uint32_t baseNode = 0, baseQueue = 0;
+    if (lane == 63 && total) { baseNode = atomicAdd(counters + 0, total); baseQueue = atomicAdd(counters + 1, total); }
+    baseNode = __shfl(baseNode, 63);
+    baseQueue = __shfl(baseQueue, 63);
+    if (!active) return;
+    uint32_t k = incl - nInterior;
+    float4 lo[4], hi[4];
+    uint32_t refs[4];
+    for (int i = 0; i < n; ++i) {
+        lo[i] = nodeLo[kids[i]];
+        hi[i] = nodeHi[kids[i]];
+        if (kids[i] < nInternal) {
+            refs[i] = baseNode + k;
+            nextQueue[baseQueue + k] = QueueEntry{ kids[i], baseNode + k };
+            ++k;
+        } else {
+            const uint32_t pos = kids[i] - nInternal;                 // sorted position = leaf row
+            const bool sph = sortedIds[pos] >= nTris;
+            refs[i] = kWideLeafBit | (sph ? kWideSphereBit : 0u) | pos;      // one primitive per leaf: count - 1 = 0
+        }
+    }
+    WideNode w;
+    setChildren(w, lo, hi, refs, n);
+    out[e.wide] = w;
+}
+
+// leaf rows in sorted order: the reference's TriAccel bits of the triangle's slot / the sphere record
+__global__ void __launch_bounds__(256) leafRows(const uint32_t* __restrict__ sortedIds, uint32_t n, uint32_t nTris,
+                                                const uint32_t* __restrict__ slotOfInput, const float4* __restrict__ triaccel,
+                                                const float4* __restrict__ spheres, float4* __restrict__ rowsA, float4* __restrict__ rowsBC)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t p = sortedIds[r];
+    if (p < nTris) {
+        const uint32_t slot = slotOfInput[p];
+        const float4 a = triaccel[(size_t)slot * 3 + 0], b = triaccel[(size_t)slot * 3 + 1], c = triaccel[(size_t)slot * 3 + 2];
+        const uint32_t k = __float_as_uint(a.w);                        // TriAccel::k (0..2)
+        rowsA[r] = make_float4(a.x, a.y, a.z, __uint_as_float((k & 3u) | (slot << 2)));
+        rowsBC[(size_t)r * 2 + 0] = make_float4(b.x, b.y, b.z, 0.0f);
+        rowsBC[(size_t)r * 2 + 1] = make_float4(c.x, c.y, c.z, 0.0f);
+    } else {
+        const uint32_t s = p - nTris;
+        rowsA[r] = spheres[s];
+        rowsBC[(size_t)r * 2 + 0] = make_float4(__uint_as_float(s), 0.0f, 0.0f, 0.0f);
+        rowsBC[(size_t)r * 2 + 1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+}
+
+struct Scratch {                    // frees whatever was allocated, whichever way the build ends
+    std::vector<void*> ptrs;
+    ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
+    template <class T> hipError_t alloc(T** p, size_t count)
+    {
+        *p = nullptr;
+        const hipError_t e = hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) ptrs.push_back(*p);
+        return e;
+    }
+};
+
+uint32_t blocks(size_t n) { return static_cast<uint32_t>((n + 255) / 256); }
+
+} // namespace
+
+struct DeviceWideBuilder::State {
+    Scratch S;
+    size_t nTris = 0, nSpheres = 0, n = 0, wideCount = 0;
+    int wideDepth = 0;
+    const uint32_t* sortedIds = nullptr;
+    float* dSpheres = nullptr;
+    WideNode* wide = nullptr;
+    std::chrono::steady_clock::time_point t0;
+};
+
+DeviceWideBuilder::DeviceWideBuilder() = default;
+DeviceWideBuilder::~DeviceWideBuilder() { delete state_; }
+
+// Phase 1: everything that needs only the scene -- boxes, sort, topology, fit, plan, wide nodes.
+int DeviceWideBuilder::topology(const float* verts, size_t nVerts, const int32_t* tris, size_t nTris, const float* spheres,
+                                size_t nSpheres, std::string& err)
+{
+    delete state_;
+    state_ = nullptr;
+    const size_t nP = nTris + nSpheres;
+    if (nP < 2 || nP > kWideMaxPrims || nVerts > 0xFFFFFFFFull) { err = "device builder: primitive count out of its range"; return YART_ERR_INVALID_ARGUMENT; }
+    State* st = new State();
+    state_ = st;
+    st->t0 = std::chrono::steady_clock::now();
+    st->nTris = nTris;
+    st->nSpheres = nSpheres;
+    Scratch& S = st->S;
+    float* dVerts; int32_t* dTris; float* dSpheres;
+    float4 *primLo, *primHi;
+    uint32_t* dBounds;
+    YART_HIP(S.alloc(&dVerts, nVerts * 3));
+    YART_HIP(S.alloc(&dTris, nTris * 5));
+    YART_HIP(S.alloc(&dSpheres, nSpheres * 4));
+    YART_HIP(S.alloc(&primLo, nP));
+    YART_HIP(S.alloc(&primHi, nP));
+    YART_HIP(S.alloc(&dBounds, 8));
+    st->dSpheres = dSpheres;
+    if (nVerts) YART_HIP(hipMemcpyAsync(dVerts, verts, nVerts * 12, hipMemcpyHostToDevice, nullptr));
+    if (nTris) YART_HIP(hipMemcpyAsync(dTris, tris, nTris * 20, hipMemcpyHostToDevice, nullptr));
+    if (nSpheres) YART_HIP(hipMemcpyAsync(dSpheres, spheres, nSpheres * 16, hipMemcpyHostToDevice, nullptr));
+    const uint32_t initBounds[8] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u };
+    YART_HIP(hipMemcpyAsync(dBounds, initBounds, sizeof initBounds, hipMemcpyHostToDevice, nullptr));
+    hipLaunchKernelGGL(primBoxes, dim3(blocks(nP)), dim3(256), 0, nullptr, dVerts, dTris, (uint32_t)nTris, dSpheres, (uint32_t)nSpheres,
+                       (uint32_t)nVerts, primLo, primHi, dBounds);
+    YART_HIP(hipGetLastError());
+
+    // Morton codes, sorted
+    uint64_t *codesA, *codesB;
+    uint32_t *idsA, *idsB;
+    YART_HIP(S.alloc(&codesA, nP));
+    YART_HIP(S.alloc(&codesB, nP));
+    YART_HIP(S.alloc(&idsA, nP));
+    YART_HIP(S.alloc(&idsB, nP));
+    hipLaunchKernelGGL(mortonCodes, dim3(blocks(nP)), dim3(256), 0, nullptr, primLo, primHi, (uint32_t)nP, dBounds, codesA, idsA);
+    YART_HIP(hipGetLastError());
+    hipcub::DoubleBuffer<uint64_t> keys(codesA, codesB);
+    hipcub::DoubleBuffer<uint32_t> vals(idsA, idsB);
+    size_t tempBytes = 0;
+    YART_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, keys, vals, (int)nP, 0, 64, nullptr));
+    char* temp;
+    YART_HIP(S.alloc(&temp, tempBytes));
+    YART_HIP(hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, keys, vals, (int)nP, 0, 64, nullptr));
+    const uint64_t* codes = keys.Current();
+    const uint32_t* sortedIds = vals.Current();
+    st->sortedIds = sortedIds;
+    uint32_t hostBounds[8];
+    YART_HIP(hipMemcpy(hostBounds, dBounds, sizeof hostBounds, hipMemcpyDeviceToHost));
+    const size_t n = hostBounds[6];                       // valid primitives: the first n sorted positions
+    if (n < 2) { err = "device builder: fewer than two valid primitives"; return YART_ERR_INVALID_ARGUMENT; }
+    st->n = n;
+
+    // topology
+    const size_t nInternal = n - 1, nNodes = 2 * n - 1;
+    uint32_t *left, *right, *parent, *depth, *dAny;
+    YART_HIP(S.alloc(&left, nInternal));
+    YART_HIP(S.alloc(&right, nInternal));
+    YART_HIP(S.alloc(&parent, nNodes));
+    YART_HIP(S.alloc(&depth, nNodes));
+    YART_HIP(S.alloc(&dAny, 64));
+    hipLaunchKernelGGL(hierarchy, dim3(blocks(nInternal)), dim3(256), 0, nullptr, codes, (int)n, left, right, parent);
+    YART_HIP(hipGetLastError());
+    YART_HIP(hipMemsetAsync(depth, 0xFF, nNodes * 4, nullptr));
+    YART_HIP(hipMemsetAsync(depth, 0, 4, nullptr));        // the root, internal node 0
+    YART_HIP(hipMemsetAsync(dAny, 0, 256, nullptr));
+    // levels, eight launches between two looks at the flags
+    uint32_t levels = 0;
+    for (bool more = true; more;) {
+        if (levels > 4096) { err = "device builder: hierarchy deeper than 4096 levels"; return YART_ERR_TREE_TOO_DEEP; }
+        for (uint32_t k = 0; k < 8; ++k)
+            hipLaunchKernelGGL(assignLevel, dim3(blocks(nInternal)), dim3(256), 0, nullptr, left, right, (uint32_t)nInternal, depth, levels + k, dAny + k);
+        YART_HIP(hipGetLastError());
+        uint32_t any[8];
+        YART_HIP(hipMemcpy(any, dAny, sizeof any, hipMemcpyDeviceToHost));
+        YART_HIP(hipMemsetAsync(dAny, 0, 256, nullptr));
+        uint32_t k = 0;
+        while (k < 8 && any[k]) ++k;
+        levels += k;
+        more = k == 8;
+    }
+
+    // boxes + collapse plan, deepest level first
+    float4 *nodeLo, *nodeHi;
+    Plan* plan;
+    YART_HIP(S.alloc(&nodeLo, nNodes));
+    YART_HIP(S.alloc(&nodeHi, nNodes));
+    YART_HIP(S.alloc(&plan, nNodes));
+    hipLaunchKernelGGL(leafNodes, dim3(blocks(n)), dim3(256), 0, nullptr, primLo, primHi, sortedIds, (uint32_t)n, nodeLo, nodeHi, plan);
+    YART_HIP(hipGetLastError());
+    for (uint32_t lv = levels; lv-- > 0;)
+        hipLaunchKernelGGL(fitLevel, dim3(blocks(nInternal)), dim3(256), 0, nullptr, left, right, (uint32_t)nInternal, depth, lv, nodeLo, nodeHi, plan);
+    YART_HIP(hipGetLastError());
+
+    // wide nodes, top-down
+    WideNode* wide;
+    QueueEntry *queueA, *queueB;
+    uint32_t* counters;
+    YART_HIP(S.alloc(&wide, nInternal));                  // a wide node swallows at least one binary node
+    YART_HIP(S.alloc(&queueA, nInternal));
+    YART_HIP(S.alloc(&queueB, nInternal));
+    YART_HIP(S.alloc(&counters, 64));
+    st->wide = wide;
+    const QueueEntry root{ 0u, 0u };
+    YART_HIP(hipMemcpyAsync(queueA, &root, sizeof root, hipMemcpyHostToDevice, nullptr));
+    const uint32_t initCounters[2] = { 1u, 0u };
+    YART_HIP(hipMemcpyAsync(counters, initCounters, sizeof initCounters, hipMemcpyHostToDevice, nullptr));
+    uint32_t nQueue = 1;
+    st->wideCount = 1;
+    while (nQueue > 0) {
+        ++st->wideDepth;
+        if (3 * st->wideDepth + 1 > kWideStack) { err = "device builder: tree deeper than the traversal stack allows"; return YART_ERR_TREE_TOO_DEEP; }
+        hipLaunchKernelGGL(emitLevel, dim3(blocks(nQueue)), dim3(256), 0, nullptr, queueA, nQueue, queueB, counters, left, right, plan,
+                           (uint32_t)nInternal, (uint32_t)nTris, sortedIds, nodeLo, nodeHi, wide);
+        YART_HIP(hipGetLastError());
+        uint32_t c[2];
+        YART_HIP(hipMemcpy(c, counters, sizeof c, hipMemcpyDeviceToHost));
+        st->wideCount = c[0];
+        nQueue = c[1];
+        YART_HIP(hipMemsetAsync(counters + 1, 0, 4, nullptr));
+        std::swap(queueA, queueB);
+    }
+    return YART_OK;
+}
+
+// Phase 2: what needs the reference's leaf order -- the leaf rows -- and the exact-size result arrays.
+int DeviceWideBuilder::finish(const void* dTriAccel, const uint32_t* slotOfInput, DeviceWide& out, std::string& err)
+{
+    out = DeviceWide{};
+    State* st = state_;
+    if (!st || st->n < 2) { err = "device builder: finish() without a topology"; return YART_ERR_INVALID_ARGUMENT; }
+    uint32_t* dSlot;
+    YART_HIP(st->S.alloc(&dSlot, st->nTris));
+    if (st->nTris) YART_HIP(hipMemcpyAsync(dSlot, slotOfInput, st->nTris * 4, hipMemcpyHostToDevice, nullptr));
+    void *nodesOut = nullptr, *rowsA = nullptr, *rowsBC = nullptr;
+    hipError_t e = hipMalloc(&nodesOut, st->wideCount * sizeof(WideNode));
+    if (e == hipSuccess) e = hipMalloc(&rowsA, st->n * 16);
+    if (e == hipSuccess) e = hipMalloc(&rowsBC, st->n * 32);
+    if (e == hipSuccess) e = hipMemcpyAsync(nodesOut, st->wide, st->wideCount * sizeof(WideNode), hipMemcpyDeviceToDevice, nullptr);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(leafRows, dim3(blocks(st->n)), dim3(256), 0, nullptr, st->sortedIds, (uint32_t)st->n, (uint32_t)st->nTris, dSlot,
+                           static_cast<const float4*>(dTriAccel), reinterpret_cast<const float4*>(st->dSpheres), static_cast<float4*>(rowsA),
+                           static_cast<float4*>(rowsBC));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        (void)hipFree(nodesOut); (void)hipFree(rowsA); (void)hipFree(rowsBC);
+        err = std::string("device builder: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? YART_ERR_OUT_OF_MEMORY : YART_ERR_HIP;
+    }
+    out.nodes = nodesOut; out.rowsA = rowsA; out.rowsBC = rowsBC;
+    out.numNodes = st->wideCount; out.numPrims = st->n; out.depth = st->wideDepth;
+    out.msBuild = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - st->t0).count();
+    delete state_;
+    state_ = nullptr;
+    return YART_OK;
+}
+
+} // namespace yart
