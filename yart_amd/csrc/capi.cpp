@@ -366,10 +366,10 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
             a->deviceBytes += dw.numNodes * sizeof(yart::WideNode) + dw.numPrims * 48;
             a->hasWide = true;
             a->wideBuiltOnDevice = true;
-            a->msWideDeviceBuild = dw.msBuild;
+            a->msWideDeviceBuild = dw.msTopology + dw.msFinish;
             if (std::getenv("YART_BUILD_TIMING"))
-                fprintf(stderr, "device wide build: %.1f ms from start to leaf rows (%zu nodes, depth %d); reference tree on the host meanwhile: %.1f ms\n",
-                        dw.msBuild, dw.numNodes, dw.depth, msRefTree);
+                fprintf(stderr, "device wide build: %.1f ms (scene upload, sort, topology, fit, plan, %zu wide nodes, depth %d) + %.1f ms (leaf rows); "
+                                "reference tree on the host meanwhile: %.1f ms\n", dw.msTopology, dw.numNodes, dw.depth, dw.msFinish, msRefTree);
         }
     } else if (st == YART_OK && wantWide) {
         st = upload(&a->dWideNodes, wide.nodes.data(), wide.nodes.size() * sizeof(yart::WideNode), a->deviceBytes);

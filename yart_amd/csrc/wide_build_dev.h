@@ -14,7 +14,9 @@ struct DeviceWide {
     void* rowsBC = nullptr;
     size_t numNodes = 0, numPrims = 0;
     int depth = 0;
-    double msBuild = 0.0;           // wall time from topology() to the end of finish()
+    double msBuild = 0.0;           // wall time from the start of topology() to the end of finish()
+    double msTopology = 0.0;        // of it: phase 1 (upload of the scene, sort, topology, fit, plan, wide nodes)
+    double msFinish = 0.0;          // and phase 2 (leaf rows, exact-size arrays)
 };
 
 class DeviceWideBuilder {

@@ -426,6 +426,7 @@ struct DeviceWideBuilder::State {
     float* dSpheres = nullptr;
     WideNode* wide = nullptr;
     std::chrono::steady_clock::time_point t0;
+    double msTopology = 0.0;
 };
 
 DeviceWideBuilder::DeviceWideBuilder() = default;
@@ -558,6 +559,8 @@ int DeviceWideBuilder::topology(const float* verts, size_t nVerts, const int32_t
         YART_HIP(hipMemsetAsync(counters + 1, 0, 4, nullptr));
         std::swap(queueA, queueB);
     }
+    YART_HIP(hipDeviceSynchronize());
+    st->msTopology = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - st->t0).count();
     return YART_OK;
 }
 
@@ -567,6 +570,7 @@ int DeviceWideBuilder::finish(const void* dTriAccel, const uint32_t* slotOfInput
     out = DeviceWide{};
     State* st = state_;
     if (!st || st->n < 2) { err = "device builder: finish() without a topology"; return YART_ERR_INVALID_ARGUMENT; }
+    const auto tFinish0 = std::chrono::steady_clock::now();
     uint32_t* dSlot;
     YART_HIP(st->S.alloc(&dSlot, st->nTris));
     if (st->nTris) YART_HIP(hipMemcpyAsync(dSlot, slotOfInput, st->nTris * 4, hipMemcpyHostToDevice, nullptr));
@@ -590,6 +594,8 @@ int DeviceWideBuilder::finish(const void* dTriAccel, const uint32_t* slotOfInput
     out.nodes = nodesOut; out.rowsA = rowsA; out.rowsBC = rowsBC;
     out.numNodes = st->wideCount; out.numPrims = st->n; out.depth = st->wideDepth;
     out.msBuild = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - st->t0).count();
+    out.msTopology = st->msTopology;
+    out.msFinish = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tFinish0).count();
     delete state_;
     state_ = nullptr;
     return YART_OK;
