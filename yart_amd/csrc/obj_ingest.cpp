@@ -67,7 +67,8 @@ struct Cursor {
             if (s != end && (*s == '+' || *s == '-')) { eNegative = *s == '-'; ++s; }
             else if (!digit(*s)) return 0.0f;           // *end is a blank, '\r' or NUL: readable
             int eDigits = 0;
-            for (; s != end && digit(*s); ++s, ++eDigits) { e *= 10; e += static_cast<int>(*s - '0'); }
+            for (; s != end && digit(*s); ++s, ++eDigits)
+                if (e < 100000) { e *= 10; e += static_cast<int>(*s - '0'); }      // saturates: pow(5, e) is 0 or inf long before (no signed overflow on hostile input)
             if (eDigits == 0) return 0.0f;
             if (eNegative) e = -e;
         }
@@ -215,7 +216,7 @@ bool loadObjScene(const std::string& folder, const std::string& file, ObjScene& 
             if (it != b.seen.end()) return it->second;
             if (k.v < 0 || static_cast<size_t>(k.v) * 3 + 2 >= v.size()) { badIndex = true; return 0; }
             for (int a = 0; a < 3; ++a) b.mesh.positions.push_back(v[static_cast<size_t>(k.v) * 3 + a]);
-            if (k.vn >= 0 && static_cast<size_t>(k.vn * 3 + 2) < vn.size()) {
+            if (k.vn >= 0 && static_cast<size_t>(k.vn) * 3 + 2 < vn.size()) {
                 for (int a = 0; a < 3; ++a) b.mesh.normals.push_back(vn[static_cast<size_t>(k.vn) * 3 + a]);
             }
             const int32_t idx = static_cast<int32_t>(b.mesh.positions.size() / 3 - 1);
