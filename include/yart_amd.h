@@ -260,6 +260,24 @@ int yart_surface_dev(YartAccel* accel, const YartRay* d_rays, const YartHit* d_h
 /* Host buffers; synchronous. */
 int yart_surface(YartAccel* accel, const YartRay* rays, const YartHit* hits, size_t n, YartSurface* out);
 
+/* ---- intersection: ray queue with pinned host mirrors ------------------------------------------
+ * For a renderer whose shading stays on the host (the reference's BSDFs, lights and Rng,
+ * src/renderer.cpp:59-129) but which submits rays in batches: device arrays for `capacity` rays and
+ * their results, mirrored in page-locked host memory.  The caller writes rays into the mirror,
+ * yart_queue_closest / _any copy them to the device (DMA from pinned memory on the queue's own stream),
+ * run the batch -- and, on request, the hit post-processing of row K on the device -- copy the results
+ * back and return when they are in the mirrors.  One batch at a time per queue; queues are independent.
+ * Used by yart_amd/cxx/wavefront.hpp; no counterpart in the reference (one ray per call). */
+typedef struct YartQueue YartQueue;
+int yart_queue_create(YartAccel* accel, size_t capacity, YartQueue** out);
+void yart_queue_destroy(YartQueue* queue);
+YartRay* yart_queue_rays(YartQueue* queue);                 /* host mirror, `capacity` entries, caller writes */
+const YartHit* yart_queue_hits(const YartQueue* queue);     /* valid after yart_queue_closest */
+const YartSurface* yart_queue_surfaces(const YartQueue* queue);   /* valid after yart_queue_closest(.., with_surface = 1) */
+const uint8_t* yart_queue_occluded(const YartQueue* queue); /* valid after yart_queue_any */
+int yart_queue_closest(YartQueue* queue, size_t n, unsigned flags, int with_surface);
+int yart_queue_any(YartQueue* queue, size_t n, unsigned flags);
+
 /* ---- Wavefront driver, device resident ----------------------------------------------
  * Replaces the per-pixel synchronous loop of the reference's renderer -- TileTask::run -> trace()
  * (src/renderer.cpp:29-136, :146-153), which calls Scene::intersect / intersectShadow one ray at a time

@@ -277,7 +277,7 @@ _ENGINE_CLOSEST = ctypes.CFUNCTYPE(ctypes.c_int, c_vp, c_vp, c_sz, c_vp, ctypes.
 _ENGINE_ANY = ctypes.CFUNCTYPE(ctypes.c_int, c_vp, c_vp, c_sz, c_vp, ctypes.c_uint)
 
 
-def reference_trace_cornell(width, height, pixels, mode=0, nthreads=8, engine=None, so=None):
+def reference_trace_cornell(width, height, pixels, mode=0, nthreads=8, engine=None, so=None, queue_api=None):
     """The reference's own trace() (src/renderer.cpp:29-136, 4096 spp, <= 10 bounces,
     Rng(y*width+x)) on the listed (x, y) pixels of a width x height frame of
     Scene::makeCornellBox with the camera of src/rt.cpp:22-28.
@@ -288,8 +288,14 @@ def reference_trace_cornell(width, height, pixels, mode=0, nthreads=8, engine=No
                 every Scene::intersect / intersectShadow of trace() is answered by those C-ABI
                 entry points through the reference's virtual Shape::intersect hook.
       mode 3 -> rgb, stats; trace() restated as the integrator of yart_amd/cxx/wavefront.hpp: all
-                listed pixels in flight, batched engine calls."""
+                listed pixels in flight, batched engine calls.
+      mode 4 -> as 3, the batches going through a YartQueue; `queue_api` = addresses of yart_queue_create,
+                _destroy, _rays, _hits, _surfaces, _occluded, _closest, _any."""
     L = ctypes.CDLL(so or REF_SO)
+    if mode == 4:
+        arr = (ctypes.c_void_p * 8)(*queue_api)
+        L.ref_set_queue_api.argtypes = [ctypes.c_void_p]
+        L.ref_set_queue_api(arr)
     L.ref_trace_cornell.restype = ctypes.c_long
     L.ref_trace_cornell.argtypes = [ctypes.c_int, ctypes.c_int, c_vp, c_sz, ctypes.c_int, ctypes.c_int, c_vp,
                                     ctypes.POINTER(c_vp), ctypes.POINTER(c_sz), ctypes.POINTER(c_vp),
@@ -313,7 +319,7 @@ def reference_trace_cornell(width, height, pixels, mode=0, nthreads=8, engine=No
         if rc < 0:
             raise RuntimeError("engine call failed inside trace()")
         return rgb, int(rc)
-    if mode == 3:
+    if mode in (3, 4):
         if rc < 0:
             raise RuntimeError("engine call failed inside the wavefront driver")
         return rgb, dict(rays=int(rc), closest_batches=int(ncl.value), largest_batch=int(nsh.value))

@@ -432,6 +432,24 @@ extern "C" {
 //   mode 3  trace() restated as a yart_amd::PathIntegrator, driven by yart_amd::WavefrontDriver: all
 //           listed pixels in flight at once, one closest-hit batch + one shadow batch per round.
 //           Returns the number of rays traced; *nClosest = closest-hit batches, *nShadow = largest batch.
+//   mode 4  as 3, with the batches going through a YartQueue (pinned mirrors of device arrays; the
+//           yart_queue_* entry points are handed over beforehand with ref_set_queue_api).
+static yart_amd::QueueApi g_queueApi;
+static bool g_queueApiSet = false;
+
+void ref_set_queue_api(void* const* fns)      // create, destroy, rays, hits, surfaces, occluded, closest, any
+{
+    g_queueApi.create = reinterpret_cast<decltype(g_queueApi.create)>(fns[0]);
+    g_queueApi.destroy = reinterpret_cast<decltype(g_queueApi.destroy)>(fns[1]);
+    g_queueApi.rays = reinterpret_cast<decltype(g_queueApi.rays)>(fns[2]);
+    g_queueApi.hits = reinterpret_cast<decltype(g_queueApi.hits)>(fns[3]);
+    g_queueApi.surfaces = reinterpret_cast<decltype(g_queueApi.surfaces)>(fns[4]);
+    g_queueApi.occluded = reinterpret_cast<decltype(g_queueApi.occluded)>(fns[5]);
+    g_queueApi.closest = reinterpret_cast<decltype(g_queueApi.closest)>(fns[6]);
+    g_queueApi.any = reinterpret_cast<decltype(g_queueApi.any)>(fns[7]);
+    g_queueApiSet = true;
+}
+
 long ref_trace_cornell(int width, int height, const int32_t* pixels, size_t nPixels, int mode, int nthreads,
                        float* rgbOut, float** closestLog, size_t* nClosest, float** shadowLog, size_t* nShadow,
                        EngineClosestFn closestFn, EngineAnyFn anyFn, void* accel, unsigned flags)
@@ -441,7 +459,8 @@ long ref_trace_cornell(int width, int height, const int32_t* pixels, size_t nPix
     std::unique_ptr<Scene> scene;
     std::shared_ptr<EngineShape> engine;
     std::unique_ptr<BvhAccel> leafOrderSource;
-    if (mode == 3) {
+    if (mode == 3 || mode == 4) {
+        if (mode == 4 && !g_queueApiSet) { fprintf(stderr, "ref_trace_cornell: mode 4 needs ref_set_queue_api\n"); return -1; }
         // the batched driver (yart_amd/cxx/wavefront.hpp) with trace() restated as its integrator
         leafOrderSource = std::make_unique<BvhAccel>(cornell);
         RefTraceIntegrator integ(cornell, leafOrderSource->triangles_, camera, pixels, nPixels);
@@ -450,6 +469,7 @@ long ref_trace_cornell(int width, int height, const int32_t* pixels, size_t nPix
         eng.any = reinterpret_cast<int (*)(YartAccel*, const YartRay*, size_t, uint8_t*, unsigned)>(anyFn);
         eng.accel = static_cast<YartAccel*>(accel);
         eng.flags = flags;
+        if (mode == 4) eng.queue = &g_queueApi;
         yart_amd::WavefrontDriver driver(eng, nPixels, nthreads);
         yart_amd::WavefrontStats st;
         try {

@@ -16,7 +16,8 @@ from yart_amd import api, scenes
 def test_library_exports_every_declared_symbol():
     L = api.lib()
     header = open(os.path.join(ROOT, "include", "yart_amd.h")).read()
-    declared = set(re.findall(r"^(?:int|void|size_t|const char\*)\s+(yart_[a-z_]+)\s*\(", header, re.M))
+    # every declaration: a line that starts with a return type (any C type, pointers included) and names a yart_ function
+    declared = set(re.findall(r"^(?:const\s+)?[A-Za-z_][A-Za-z0-9_]*\s*\*?\s+\*?(yart_[a-z0-9_]+)\s*\(", header, re.M))
     assert declared, "no declarations found"
     assert declared == set(api.EXPORTS)
     for name in declared:

@@ -89,6 +89,25 @@ def test_wavefront_driver_reproduces_reference_image(rule):
 
 @needs_ref
 @pytest.mark.gpu
+def test_wavefront_driver_over_pinned_queue_reproduces_reference_image():
+    """The same driver with its batches going through a YartQueue (device arrays mirrored in pinned host
+    memory, yart_queue_*): bit-identical pixels again."""
+    g = load_golden("g4_trace.npz")
+    w, h = (int(v) for v in g["frame"])
+    acc = api.Accel(g["verts"], g["tris"], g["spheres"], device=0)
+    L = api.lib()
+    fc = ctypes.cast(L.yart_intersect_closest, ctypes.c_void_p)
+    fa = ctypes.cast(L.yart_intersect_any, ctypes.c_void_p)
+    qapi = [ctypes.cast(getattr(L, "yart_queue_" + n), ctypes.c_void_p).value
+            for n in ("create", "destroy", "rays", "hits", "surfaces", "occluded", "closest", "any")]
+    rgb, info = orc.reference_trace_cornell(w, h, g["pixels"], mode=4, nthreads=4, engine=(fc, fa, acc._h, 0), queue_api=qapi)
+    assert np.array_equal(rgb.view(np.uint32), g["rgb"].view(np.uint32))
+    assert info["rays"] == int(g["stream_counts"].sum())
+    acc.close()
+
+
+@needs_ref
+@pytest.mark.gpu
 @pytest.mark.parametrize("rule", ["reference", "default"])
 def test_reference_renderer_drives_engine(rule):
     g = load_golden("g4_trace.npz")

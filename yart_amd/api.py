@@ -45,6 +45,8 @@ EXPORTS = [
     "yart_wavefront_create", "yart_wavefront_destroy", "yart_wavefront_render_diffuse",
     "yart_tiles_count", "yart_tiles_list", "yart_tiles_rank_pixels",
     "yart_comm_unique_id", "yart_comm_create", "yart_comm_destroy", "yart_frame_gather",
+    "yart_queue_create", "yart_queue_destroy", "yart_queue_rays", "yart_queue_hits", "yart_queue_surfaces",
+    "yart_queue_occluded", "yart_queue_closest", "yart_queue_any",
 ]
 
 

@@ -555,6 +555,93 @@ int yart_intersect_any(YartAccel* accel, const YartRay* rays, size_t n, uint8_t*
     return hostCall(accel, rays, n, nullptr, occluded, flags);
 }
 
+struct YartQueue {
+    YartAccel* accel = nullptr;
+    size_t capacity = 0;
+    hipStream_t stream = nullptr;
+    void* host = nullptr;       // one pinned block: rays | hits | surfaces | occluded
+    void* dev = nullptr;        // the same layout on the device
+    size_t offHits = 0, offSurf = 0, offOcc = 0, bytes = 0;
+};
+
+int yart_queue_create(YartAccel* accel, size_t capacity, YartQueue** out)
+{
+    if (!accel || !out || capacity == 0 || capacity > 0x7FFFFFFFu) return fail(YART_ERR_INVALID_ARGUMENT, "yart_queue_create: bad argument");
+    *out = nullptr;
+    DeviceGuard guard(accel->device);
+    if (!guard.ok) return fail(YART_ERR_NO_DEVICE, "hipSetDevice failed");
+    auto q = std::make_unique<YartQueue>();
+    q->accel = accel;
+    q->capacity = capacity;
+    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+    q->offHits = up(capacity * sizeof(YartRay));
+    q->offSurf = q->offHits + up(capacity * sizeof(YartHit));
+    q->offOcc = q->offSurf + up(capacity * sizeof(YartSurface));
+    q->bytes = q->offOcc + up(capacity);
+    hipError_t e = hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc(&q->host, q->bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(&q->dev, q->bytes);
+    if (e != hipSuccess) {
+        (void)hipHostFree(q->host); (void)hipFree(q->dev);
+        if (q->stream) (void)hipStreamDestroy(q->stream);
+        return fail(YART_ERR_OUT_OF_MEMORY, std::string("yart_queue_create: ") + hipGetErrorString(e));
+    }
+    *out = q.release();
+    return YART_OK;
+}
+
+void yart_queue_destroy(YartQueue* q)
+{
+    if (!q) return;
+    {
+        DeviceGuard guard(q->accel->device);
+        (void)hipStreamSynchronize(q->stream);
+        (void)hipHostFree(q->host);
+        (void)hipFree(q->dev);
+        (void)hipStreamDestroy(q->stream);
+    }
+    delete q;
+}
+
+YartRay* yart_queue_rays(YartQueue* q) { return q ? static_cast<YartRay*>(q->host) : nullptr; }
+const YartHit* yart_queue_hits(const YartQueue* q) { return q ? reinterpret_cast<const YartHit*>(static_cast<const char*>(q->host) + q->offHits) : nullptr; }
+const YartSurface* yart_queue_surfaces(const YartQueue* q) { return q ? reinterpret_cast<const YartSurface*>(static_cast<const char*>(q->host) + q->offSurf) : nullptr; }
+const uint8_t* yart_queue_occluded(const YartQueue* q) { return q ? reinterpret_cast<const uint8_t*>(static_cast<const char*>(q->host) + q->offOcc) : nullptr; }
+
+static int queueRun(YartQueue* q, size_t n, unsigned flags, bool any, bool surface)
+{
+    if (!q) return fail(YART_ERR_INVALID_ARGUMENT, "null queue");
+    if (n == 0) return YART_OK;
+    if (n > q->capacity) return fail(YART_ERR_INVALID_ARGUMENT, "yart_queue: batch larger than the queue's capacity");
+    DeviceGuard guard(q->accel->device);
+    if (!guard.ok) return fail(YART_ERR_NO_DEVICE, "hipSetDevice failed");
+    char* h = static_cast<char*>(q->host);
+    char* d = static_cast<char*>(q->dev);
+    hipError_t e = hipMemcpyAsync(d, h, n * sizeof(YartRay), hipMemcpyHostToDevice, q->stream);
+    if (e != hipSuccess) return failHip(e, "hipMemcpyAsync H2D");
+    int st;
+    if (any) {
+        st = yart_intersect_any_dev(q->accel, reinterpret_cast<const YartRay*>(d), n, reinterpret_cast<uint8_t*>(d + q->offOcc), flags, q->stream);
+        if (st != YART_OK) return st;
+        e = hipMemcpyAsync(h + q->offOcc, d + q->offOcc, n, hipMemcpyDeviceToHost, q->stream);
+    } else {
+        st = yart_intersect_closest_dev(q->accel, reinterpret_cast<const YartRay*>(d), n, reinterpret_cast<YartHit*>(d + q->offHits), flags, q->stream);
+        if (st != YART_OK) return st;
+        e = hipMemcpyAsync(h + q->offHits, d + q->offHits, n * sizeof(YartHit), hipMemcpyDeviceToHost, q->stream);
+        if (e == hipSuccess && surface) {
+            st = yart_surface_dev(q->accel, reinterpret_cast<const YartRay*>(d), reinterpret_cast<const YartHit*>(d + q->offHits), n,
+                                  reinterpret_cast<YartSurface*>(d + q->offSurf), q->stream);
+            if (st != YART_OK) return st;
+            e = hipMemcpyAsync(h + q->offSurf, d + q->offSurf, n * sizeof(YartSurface), hipMemcpyDeviceToHost, q->stream);
+        }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(q->stream);
+    return e == hipSuccess ? YART_OK : failHip(e, "yart_queue copy / synchronise");
+}
+
+int yart_queue_closest(YartQueue* q, size_t n, unsigned flags, int with_surface) { return queueRun(q, n, flags, false, with_surface != 0); }
+int yart_queue_any(YartQueue* q, size_t n, unsigned flags) { return queueRun(q, n, flags, true, false); }
+
 size_t yart_accel_num_nodes(const YartAccel* a) { return a ? a->tri.nodes.size() : 0; }
 size_t yart_accel_num_triangles(const YartAccel* a) { return a ? a->tri.triaccel.size() : 0; }
 size_t yart_accel_num_spheres(const YartAccel* a) { return a ? a->numSpheres : 0; }

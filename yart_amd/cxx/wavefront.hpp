@@ -39,7 +39,27 @@ public:
     virtual ~PathIntegrator() = default;
     virtual bool nextPath(size_t slot, YartRay* ray) = 0;
     virtual bool onClosest(size_t slot, const YartRay& ray, const YartHit& hit, YartRay* shadowRay) = 0;
+    // queue mode with Engine::surfaces: the hit with its normals (row K computed on the device); default: drop them
+    virtual bool onClosestSurface(size_t slot, const YartRay& ray, const YartSurface& s, YartRay* shadowRay)
+    {
+        const YartHit hit = { s.t, s.u, s.v, s.prim };
+        return onClosest(slot, ray, hit, shadowRay);
+    }
     virtual bool onShadow(size_t slot, bool occluded, YartRay* nextRay) = 0;
+};
+
+// The yart_queue_* entry points (include/yart_amd.h): device arrays mirrored in pinned host memory.  With
+// them the driver writes every batch straight into the pinned mirror and reads the results from there:
+// no staging copies on the host, DMA both ways, optionally the hit post-processing on the device.
+struct QueueApi {
+    int (*create)(YartAccel*, size_t, YartQueue**) = nullptr;
+    void (*destroy)(YartQueue*) = nullptr;
+    YartRay* (*rays)(YartQueue*) = nullptr;
+    const YartHit* (*hits)(const YartQueue*) = nullptr;
+    const YartSurface* (*surfaces)(const YartQueue*) = nullptr;
+    const uint8_t* (*occluded)(const YartQueue*) = nullptr;
+    int (*closest)(YartQueue*, size_t, unsigned, int) = nullptr;
+    int (*any)(YartQueue*, size_t, unsigned) = nullptr;
 };
 
 struct Engine {
@@ -47,6 +67,8 @@ struct Engine {
     int (*any)(YartAccel*, const YartRay*, size_t, uint8_t*, unsigned) = nullptr;
     YartAccel* accel = nullptr;
     unsigned flags = YART_DEFAULT;
+    const QueueApi* queue = nullptr;      // set: batches go through a YartQueue instead of the host-buffer calls
+    bool surfaces = false;                // queue mode: also fetch YartSurface records (onClosestSurface)
 };
 
 inline Engine linkedEngine(YartAccel* accel, unsigned flags = YART_DEFAULT)
@@ -57,6 +79,13 @@ inline Engine linkedEngine(YartAccel* accel, unsigned flags = YART_DEFAULT)
     e.accel = accel;
     e.flags = flags;
     return e;
+}
+
+inline const QueueApi* linkedQueueApi()
+{
+    static const QueueApi api = { &yart_queue_create, &yart_queue_destroy, &yart_queue_rays, &yart_queue_hits,
+                                  &yart_queue_surfaces, &yart_queue_occluded, &yart_queue_closest, &yart_queue_any };
+    return &api;
 }
 
 struct WavefrontStats {
@@ -160,6 +189,15 @@ public:
         std::vector<uint8_t> occ;
         WavefrontStats st;
         ids.reserve(nSlots_);
+        struct QueueHolder {
+            const QueueApi* api = nullptr;
+            YartQueue* q = nullptr;
+            ~QueueHolder() { if (q) api->destroy(q); }
+        } qh;
+        if (engine_.queue) {
+            qh.api = engine_.queue;
+            check(qh.api->create(engine_.accel, nSlots_, &qh.q));
+        }
         for (;;) {
             // slots without a path start their next one (sequential per slot, parallel across slots)
             std::atomic<uint64_t> started{ 0 };
@@ -172,31 +210,57 @@ public:
 
             collect(state, kClosest, ids);
             if (!ids.empty()) {
-                gather(ids, ray, batch);
-                hits.resize(ids.size());
-                check(engine_.closest(engine_.accel, batch.data(), batch.size(), hits.data(), engine_.flags));
                 st.closestRays += ids.size();
                 st.closestBatches++;
                 if (ids.size() > st.largestBatch) st.largestBatch = ids.size();
-                parallelFor(ids.size(), [&](size_t i) {
-                    const uint32_t s = ids[i];
-                    YartRay shadow;
-                    if (integ.onClosest(s, batch[i], hits[i], &shadow)) { ray[s] = shadow; state[s] = kShadow; }
-                    else state[s] = kIdle;
-                });
+                if (qh.q) {
+                    // straight into the pinned mirror of the device queue, results read from the mirrors
+                    YartRay* qr = qh.api->rays(qh.q);
+                    parallelFor(ids.size(), [&](size_t i) { qr[i] = ray[ids[i]]; });
+                    check(qh.api->closest(qh.q, ids.size(), engine_.flags, engine_.surfaces ? 1 : 0));
+                    const YartHit* qhits = qh.api->hits(qh.q);
+                    const YartSurface* qs = qh.api->surfaces(qh.q);
+                    parallelFor(ids.size(), [&](size_t i) {
+                        const uint32_t s = ids[i];
+                        YartRay shadow;
+                        const bool more = engine_.surfaces ? integ.onClosestSurface(s, qr[i], qs[i], &shadow)
+                                                           : integ.onClosest(s, qr[i], qhits[i], &shadow);
+                        if (more) { ray[s] = shadow; state[s] = kShadow; }
+                        else state[s] = kIdle;
+                    });
+                } else {
+                    gather(ids, ray, batch);
+                    hits.resize(ids.size());
+                    check(engine_.closest(engine_.accel, batch.data(), batch.size(), hits.data(), engine_.flags));
+                    parallelFor(ids.size(), [&](size_t i) {
+                        const uint32_t s = ids[i];
+                        YartRay shadow;
+                        if (integ.onClosest(s, batch[i], hits[i], &shadow)) { ray[s] = shadow; state[s] = kShadow; }
+                        else state[s] = kIdle;
+                    });
+                }
             }
 
             collect(state, kShadow, ids);
             if (!ids.empty()) {
-                gather(ids, ray, batch);
-                occ.resize(ids.size());
-                check(engine_.any(engine_.accel, batch.data(), batch.size(), occ.data(), engine_.flags));
                 st.shadowRays += ids.size();
                 st.shadowBatches++;
+                const uint8_t* occluded;
+                if (qh.q) {
+                    YartRay* qr = qh.api->rays(qh.q);
+                    parallelFor(ids.size(), [&](size_t i) { qr[i] = ray[ids[i]]; });
+                    check(qh.api->any(qh.q, ids.size(), engine_.flags));
+                    occluded = qh.api->occluded(qh.q);
+                } else {
+                    gather(ids, ray, batch);
+                    occ.resize(ids.size());
+                    check(engine_.any(engine_.accel, batch.data(), batch.size(), occ.data(), engine_.flags));
+                    occluded = occ.data();
+                }
                 parallelFor(ids.size(), [&](size_t i) {
                     const uint32_t s = ids[i];
                     YartRay next;
-                    if (integ.onShadow(s, occ[i] != 0, &next)) { ray[s] = next; state[s] = kClosest; }
+                    if (integ.onShadow(s, occluded[i] != 0, &next)) { ray[s] = next; state[s] = kClosest; }
                     else state[s] = kIdle;
                 });
             }
