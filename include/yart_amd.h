@@ -207,6 +207,14 @@ int yart_accel_get_wide(const YartAccel* accel, void* nodes_out, void* rows_a_ou
  * 0 if the host builder made it (the default: binned SAH, better trees, seconds for 10^7 primitives).
  * ms_out (optional): wall milliseconds of the device build. */
 int yart_accel_wide_built_on_device(const YartAccel* accel, double* ms_out);
+/* 1 if the reference's own arrays of this accel -- the flattened nodes in the reference's order, the TriAccel
+ * records in its leaf order: what BvhAccel's constructor builds on one host thread, src/bvhaccel.cpp:100-151,
+ * :215-234, :309-363 -- were built on the GPU as well (YART_BUILD_DEVICE=1, triangle count >= 1024, no NaN
+ * coordinate; YART_BUILD_DEVICE_REF=0 keeps this build on the host), bit for bit the arrays of the host
+ * builder; 0 if the host built them.  Optional outputs: wall milliseconds of that build, the ranges whose
+ * one-sided midpoint split was settled by std::nth_element on the host, and the degenerate triangles whose
+ * TriAccel record (it holds NaNs) was computed on the host. */
+int yart_accel_ref_built_on_device(const YartAccel* accel, double* ms_out, size_t* host_median_splits, size_t* host_projections);
 /* Depth of the triangle tree (root = 1) and bytes resident in HBM. */
 int yart_accel_depth(const YartAccel* accel);
 size_t yart_accel_device_bytes(const YartAccel* accel);

@@ -37,7 +37,7 @@ EXPORTS = [
     "yart_accel_get_nodes", "yart_accel_get_triaccel", "yart_accel_depth",
     "yart_accel_device_bytes", "yart_build_host", "yart_status_string", "yart_last_error",
     "yart_accel_profile_enable", "yart_accel_profile_read",
-    "yart_build_wide_host", "yart_accel_num_wide_nodes", "yart_accel_num_wide_prims", "yart_accel_wide_depth", "yart_accel_get_wide", "yart_accel_wide_built_on_device",
+    "yart_build_wide_host", "yart_accel_num_wide_nodes", "yart_accel_num_wide_prims", "yart_accel_wide_depth", "yart_accel_get_wide", "yart_accel_wide_built_on_device", "yart_accel_ref_built_on_device",
     "yart_obj_load", "yart_obj_free", "yart_obj_num_meshes", "yart_obj_num_vertices", "yart_obj_num_triangles",
     "yart_obj_num_materials", "yart_obj_num_spheres", "yart_obj_get", "yart_obj_mesh_name", "yart_obj_material_name",
     "yart_film_tonemap", "yart_film_write_bmp",
@@ -122,6 +122,7 @@ def lib():
     L.yart_accel_depth.argtypes = [_vp]
     L.yart_accel_wide_depth.argtypes = [_vp]
     L.yart_accel_wide_built_on_device.argtypes = [_vp, ctypes.POINTER(ctypes.c_double)]
+    L.yart_accel_ref_built_on_device.argtypes = [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
     L.yart_accel_get_wide.argtypes = [_vp, _vp, _vp, _vp]
     L.yart_accel_get_nodes.argtypes = [_vp, _vp]
     L.yart_accel_get_triaccel.argtypes = [_vp, _vp]
@@ -318,6 +319,14 @@ class Accel:
         """-> (bool, milliseconds) : whether the GPU built the 4-wide tree (YART_BUILD_DEVICE=1) and how long it took."""
         ms = ctypes.c_double()
         return bool(lib().yart_accel_wide_built_on_device(self._h, ctypes.byref(ms))), ms.value
+
+    @property
+    def ref_built_on_device(self):
+        """-> (bool, milliseconds, ranges split at the median on the host, degenerate triangles projected on the host):
+        whether the GPU built the reference's own tree and TriAccel records too (YART_BUILD_DEVICE=1)."""
+        ms, med, prj = ctypes.c_double(), ctypes.c_size_t(), ctypes.c_size_t()
+        on = lib().yart_accel_ref_built_on_device(self._h, ctypes.byref(ms), ctypes.byref(med), ctypes.byref(prj))
+        return bool(on), ms.value, med.value, prj.value
 
     def wide(self):
         """-> (nodes uint32 [nNodes, 16], rowsA float32 [nPrims, 4], rowsBC float32 [nPrims, 8]) of the

@@ -18,6 +18,16 @@ struct YartAccel {
     int numCUs = 0;
     yart::TriangleBvh tri;            // host copies (nodes / triaccel kept for introspection)
     size_t numTriPairs = 0, numSphPairs = 0, numSpheres = 0;
+    size_t numTriangles = 0, numNodes = 0;   // sizes of the reference's arrays, wherever they were built
+    // YART_BUILD_DEVICE=1 and ref_build_dev.hip took the scene: the reference's arrays exist on the device only
+    // (dRefNodes, dTriAccel, dSlotOfInput); tri.nodes / tri.triaccel stay empty, tri.slotOfInput is fetched on
+    // first use (yart_accel_set_surface_data) under hostCopyMutex.
+    bool refBuiltOnDevice = false;
+    double msRefDeviceBuild = 0.0;
+    size_t refHostMedianSplits = 0, refHostProjections = 0;
+    void* dRefNodes = nullptr;
+    void* dSlotOfInput = nullptr;
+    std::mutex hostCopyMutex;
     int sphDepth = 0;
     float sceneLo[3], sceneHi[3];     // bounds of everything, for the sort key grid
     // device memory

@@ -270,6 +270,11 @@ void projectTriangle(YartTriAccel& ta, const float* a, const float* b, const flo
 
 } // namespace
 
+void projectTriangleHost(YartTriAccel& ta, const float* a, const float* b, const float* c, int32_t triIdx, int32_t meshIdx)
+{
+    projectTriangle(ta, a, b, c, triIdx, meshIdx);
+}
+
 int buildTriangleBvh(const float* verts, size_t nVerts, const int32_t* tris, size_t nTris,
                      TriangleBvh& out, std::string& err)
 {

@@ -71,4 +71,8 @@ int buildTriangleBvh(const float* verts, size_t nVerts, const int32_t* tris, siz
                      TriangleBvh& out, std::string& err);
 int buildSphereBvh(const float* spheres, size_t nSpheres, SphereBvh& out, std::string& err);
 
+// One TriAccel record (include/triaccel.h:54-108) with the host's arithmetic; the device builder
+// (ref_build_dev.hip) uses it for the degenerate triangles whose records hold NaNs.
+void projectTriangleHost(YartTriAccel& ta, const float* a, const float* b, const float* c, int32_t triIdx, int32_t meshIdx);
+
 } // namespace yart

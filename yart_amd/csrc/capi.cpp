@@ -23,6 +23,7 @@
 #include "traverse.h"
 #include "wide_build.h"
 #include "wide_build_dev.h"
+#include "ref_build_dev.h"
 #include "obj_ingest.h"
 #include "task_pool.h"
 
@@ -314,10 +315,34 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
             devStatus = devBuilder.topology(verts, n_verts, tris, n_tris, spheres, n_spheres, devErr);
         });
     }
-    int st = yart::buildTriangleBvh(verts, n_verts, tris, n_tris, a->tri, err);
+    // ... and so is the reference's own tree (ref_build_dev.hip), bit for bit, once the scene is on the device;
+    // YART_BUILD_DEVICE_REF=0 keeps that one on the host (the two builds then overlap as before)
+    const char* devRefEnv = std::getenv("YART_BUILD_DEVICE_REF");
+    const bool wantDeviceRef = wantDeviceBuild && !(devRefEnv && devRefEnv[0] == '0') && n_tris >= 1024;
+    DeviceGuard guard(device);
+    if (!guard.ok) {
+        if (devThread.joinable()) devThread.join();
+        delete a;
+        return fail(YART_ERR_NO_DEVICE, "hipSetDevice failed");
+    }
     yart::SphereBvh sph;
-    if (st == YART_OK) st = yart::buildSphereBvh(spheres, n_spheres, sph, err);
-    if (devThread.joinable()) devThread.join();
+    yart::DeviceRefTree devRef;
+    bool refOnDevice = false;
+    int st = YART_OK;
+    if (wantDeviceRef) {
+        st = yart::buildSphereBvh(spheres, n_spheres, sph, err);       // on the host while the device sorts
+        devThread.join();
+        if (st == YART_OK && devStatus == YART_OK) {
+            bool useHost = false;
+            st = yart::buildReferenceTreeDevice(devBuilder.deviceVerts(), verts, n_verts, devBuilder.deviceTris(), tris, n_tris, devRef, &useHost, err);
+            refOnDevice = st == YART_OK && !useHost;
+        }
+        if (st == YART_OK && !refOnDevice) st = yart::buildTriangleBvh(verts, n_verts, tris, n_tris, a->tri, err);
+    } else {
+        st = yart::buildTriangleBvh(verts, n_verts, tris, n_tris, a->tri, err);
+        if (st == YART_OK) st = yart::buildSphereBvh(spheres, n_spheres, sph, err);
+        if (devThread.joinable()) devThread.join();
+    }
     const double msRefTree = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tBuild0).count();
     const bool useDeviceBuild = wantDeviceBuild && devStatus == YART_OK;
     yart::WideBvh wide;
@@ -327,8 +352,11 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
         if (const char* v = std::getenv("YART_WIDE_LEAF")) maxLeaf = std::atoi(v);
         st = yart::buildWideBvh(verts, n_verts, tris, n_tris, a->tri, spheres, n_spheres, maxLeaf, wide, err);
     }
-    if (st != YART_OK) { delete a; return fail(st, err); }
-    a->numTriPairs = a->tri.pairs.size();
+    if (st != YART_OK) { devRef.release(); delete a; return fail(st, err); }
+    a->numTriPairs = refOnDevice ? devRef.numPairs : a->tri.pairs.size();
+    a->numTriangles = n_tris;
+    a->numNodes = refOnDevice ? devRef.numNodes : a->tri.nodes.size();
+    if (refOnDevice) a->tri.depth = devRef.depth;
     a->numSphPairs = sph.pairs.size();
     a->numSpheres = n_spheres;
     a->sphDepth = sph.depth;
@@ -341,24 +369,43 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
             if (r.hi[c] > a->sceneHi[c]) a->sceneHi[c] = r.hi[c];
         }
     };
-    if (n_tris) growBy(a->tri.pairs[0].child[0]);
+    if (refOnDevice) {
+        yart::DevNodeRec root;
+        std::memcpy(root.lo, devRef.rootLo, 12);
+        std::memcpy(root.hi, devRef.rootHi, 12);
+        growBy(root);
+    } else if (n_tris) growBy(a->tri.pairs[0].child[0]);
     if (n_spheres) growBy(sph.pairs[0].child[0]);
 
-    DeviceGuard guard(device);
-    if (!guard.ok) { delete a; return fail(YART_ERR_NO_DEVICE, "hipSetDevice failed"); }
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete a; return fail(YART_ERR_NO_DEVICE, "hipGetDeviceProperties failed"); }
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { devRef.release(); delete a; return fail(YART_ERR_NO_DEVICE, "hipGetDeviceProperties failed"); }
     a->numCUs = prop.multiProcessorCount;
 
-    st = upload(&a->dTriPairs, a->tri.pairs.data(), a->tri.pairs.size() * sizeof(yart::DevNodePair), a->deviceBytes);
-    if (st == YART_OK) st = upload(&a->dTriAccel, a->tri.triaccel.data(), a->tri.triaccel.size() * sizeof(YartTriAccel), a->deviceBytes);
+    if (refOnDevice) {
+        // the builder's arrays are the accel's: nothing is uploaded, nothing exists on the host
+        a->dTriPairs = devRef.pairs;
+        a->dTriAccel = devRef.triaccel;
+        a->dRefNodes = devRef.nodes;
+        a->dSlotOfInput = devRef.slotOfInput;
+        a->deviceBytes += devRef.numPairs * sizeof(yart::DevNodePair) + n_tris * (sizeof(YartTriAccel) + 4) + devRef.numNodes * sizeof(YartBvhNode);
+        a->refBuiltOnDevice = true;
+        a->msRefDeviceBuild = devRef.ms;
+        a->refHostMedianSplits = devRef.medianSplitsOnHost;
+        a->refHostProjections = devRef.projectionsOnHost;
+        if (std::getenv("YART_BUILD_TIMING"))
+            fprintf(stderr, "device reference-tree build: %.1f ms (%zu nodes, depth %d; on the host: %zu median splits, %zu degenerate projections)\n",
+                    devRef.ms, devRef.numNodes, devRef.depth, devRef.medianSplitsOnHost, devRef.projectionsOnHost);
+    } else {
+        st = upload(&a->dTriPairs, a->tri.pairs.data(), a->tri.pairs.size() * sizeof(yart::DevNodePair), a->deviceBytes);
+        if (st == YART_OK) st = upload(&a->dTriAccel, a->tri.triaccel.data(), a->tri.triaccel.size() * sizeof(YartTriAccel), a->deviceBytes);
+    }
     if (st == YART_OK) st = upload(&a->dSphPairs, sph.pairs.data(), sph.pairs.size() * sizeof(yart::DevNodePair), a->deviceBytes);
     if (st == YART_OK) st = upload(&a->dSphRecs, sph.records.data(), sph.records.size() * sizeof(float), a->deviceBytes);
     if (st == YART_OK) st = upload(&a->dSphIndex, sph.index.data(), sph.index.size() * sizeof(uint32_t), a->deviceBytes);
     if (st == YART_OK && useDeviceBuild) {
         // second phase of the device build: leaf rows from the reference's TriAccel records and leaf order
         yart::DeviceWide dw;
-        st = devBuilder.finish(a->dTriAccel, a->tri.slotOfInput.data(), dw, err);
+        st = devBuilder.finish(a->dTriAccel, refOnDevice ? static_cast<const uint32_t*>(a->dSlotOfInput) : a->tri.slotOfInput.data(), refOnDevice, dw, err);
         if (st != YART_OK) st = fail(st, err);
         else {
             a->dWideNodes = dw.nodes; a->dWideRowsA = dw.rowsA; a->dWideRowsBC = dw.rowsBC;
@@ -413,6 +460,8 @@ void yart_accel_destroy(YartAccel* a)
         DeviceGuard guard(a->device);
         (void)hipFree(a->dTriPairs);
         (void)hipFree(a->dTriAccel);
+        (void)hipFree(a->dRefNodes);
+        (void)hipFree(a->dSlotOfInput);
         (void)hipFree(a->dSphPairs);
         (void)hipFree(a->dSphRecs);
         (void)hipFree(a->dSphIndex);
@@ -642,8 +691,8 @@ static int queueRun(YartQueue* q, size_t n, unsigned flags, bool any, bool surfa
 int yart_queue_closest(YartQueue* q, size_t n, unsigned flags, int with_surface) { return queueRun(q, n, flags, false, with_surface != 0); }
 int yart_queue_any(YartQueue* q, size_t n, unsigned flags) { return queueRun(q, n, flags, true, false); }
 
-size_t yart_accel_num_nodes(const YartAccel* a) { return a ? a->tri.nodes.size() : 0; }
-size_t yart_accel_num_triangles(const YartAccel* a) { return a ? a->tri.triaccel.size() : 0; }
+size_t yart_accel_num_nodes(const YartAccel* a) { return a ? a->numNodes : 0; }
+size_t yart_accel_num_triangles(const YartAccel* a) { return a ? a->numTriangles : 0; }
 size_t yart_accel_num_spheres(const YartAccel* a) { return a ? a->numSpheres : 0; }
 int yart_accel_depth(const YartAccel* a) { return a ? a->tri.depth : 0; }
 size_t yart_accel_device_bytes(const YartAccel* a) { return a ? a->deviceBytes : 0; }
@@ -651,6 +700,11 @@ size_t yart_accel_device_bytes(const YartAccel* a) { return a ? a->deviceBytes :
 int yart_accel_get_nodes(const YartAccel* a, YartBvhNode* out)
 {
     if (!a || !out) return fail(YART_ERR_INVALID_ARGUMENT, "null argument");
+    if (a->refBuiltOnDevice) {
+        DeviceGuard guard(a->device);
+        const hipError_t e = hipMemcpy(out, a->dRefNodes, a->numNodes * sizeof(YartBvhNode), hipMemcpyDeviceToHost);
+        return e == hipSuccess ? YART_OK : failHip(e, "hipMemcpy D2H");
+    }
     std::memcpy(out, a->tri.nodes.data(), a->tri.nodes.size() * sizeof(YartBvhNode));
     return YART_OK;
 }
@@ -658,6 +712,11 @@ int yart_accel_get_nodes(const YartAccel* a, YartBvhNode* out)
 int yart_accel_get_triaccel(const YartAccel* a, YartTriAccel* out)
 {
     if (!a || !out) return fail(YART_ERR_INVALID_ARGUMENT, "null argument");
+    if (a->refBuiltOnDevice) {
+        DeviceGuard guard(a->device);
+        const hipError_t e = hipMemcpy(out, a->dTriAccel, a->numTriangles * sizeof(YartTriAccel), hipMemcpyDeviceToHost);
+        return e == hipSuccess ? YART_OK : failHip(e, "hipMemcpy D2H");
+    }
     std::memcpy(out, a->tri.triaccel.data(), a->tri.triaccel.size() * sizeof(YartTriAccel));
     return YART_OK;
 }
@@ -669,6 +728,14 @@ int yart_accel_wide_built_on_device(const YartAccel* a, double* ms_out)
 {
     if (ms_out) *ms_out = a ? a->msWideDeviceBuild : 0.0;
     return a && a->wideBuiltOnDevice ? 1 : 0;
+}
+
+int yart_accel_ref_built_on_device(const YartAccel* a, double* ms_out, size_t* host_median_splits, size_t* host_projections)
+{
+    if (ms_out) *ms_out = a ? a->msRefDeviceBuild : 0.0;
+    if (host_median_splits) *host_median_splits = a ? a->refHostMedianSplits : 0;
+    if (host_projections) *host_projections = a ? a->refHostProjections : 0;
+    return a && a->refBuiltOnDevice ? 1 : 0;
 }
 
 int yart_accel_get_wide(const YartAccel* a, void* nodes_out, void* rows_a_out, void* rows_bc_out)
@@ -765,7 +832,17 @@ int yart_accel_set_surface_data(YartAccel* a, const float* verts, size_t n_verts
                                 const float* normals, const float* spheres, size_t n_spheres)
 {
     if (!a) return fail(YART_ERR_INVALID_ARGUMENT, "accel is null");
-    if (n_tris != a->tri.triaccel.size() || n_spheres != a->numSpheres || a->tri.slotOfInput.size() != n_tris)
+    if (a->refBuiltOnDevice && n_tris == a->numTriangles) {
+        // the leaf order lives on the device: fetched once
+        std::lock_guard<std::mutex> lock(a->hostCopyMutex);
+        if (a->tri.slotOfInput.size() != n_tris) {
+            DeviceGuard guard(a->device);
+            a->tri.slotOfInput.resize(n_tris);
+            const hipError_t e = hipMemcpy(a->tri.slotOfInput.data(), a->dSlotOfInput, n_tris * sizeof(uint32_t), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { a->tri.slotOfInput.clear(); return failHip(e, "hipMemcpy D2H"); }
+        }
+    }
+    if (n_tris != a->numTriangles || n_spheres != a->numSpheres || a->tri.slotOfInput.size() != n_tris)
         return fail(YART_ERR_INVALID_ARGUMENT, "yart_accel_set_surface_data: not the scene the accel was created from");
     if ((n_tris && (!verts || !tris || !normals)) || (n_spheres && !spheres))
         return fail(YART_ERR_INVALID_ARGUMENT, "yart_accel_set_surface_data: null argument");
@@ -809,7 +886,7 @@ int yart_surface_dev(YartAccel* a, const YartRay* d_rays, const YartHit* d_hits,
     if (n == 0) return YART_OK;
     if (!d_rays || !d_hits || !d_out) return fail(YART_ERR_INVALID_ARGUMENT, "yart_surface_dev: null argument");
     if (n > 0xFFFFFFFFull / 2) return fail(YART_ERR_INVALID_ARGUMENT, "yart_surface_dev: batch too large");
-    if ((a->tri.triaccel.size() && !a->dSurfRows) || (a->numSpheres && !a->dSurfSpheres))
+    if ((a->numTriangles && !a->dSurfRows) || (a->numSpheres && !a->dSurfSpheres))
         return fail(YART_ERR_INVALID_ARGUMENT, "yart_surface_dev: call yart_accel_set_surface_data first");
     DeviceGuard guard(a->device);
     if (!guard.ok) return fail(YART_ERR_NO_DEVICE, "hipSetDevice failed");

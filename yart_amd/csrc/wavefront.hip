@@ -325,7 +325,7 @@ int yart_wavefront_create(YartAccel* accel, size_t slots, YartWavefront** out)
     if (!accel || !out) return yart::failStatus(YART_ERR_INVALID_ARGUMENT, "yart_wavefront_create: null argument");
     *out = nullptr;
     if (slots < 1 || slots > (size_t(1) << 27)) return yart::failStatus(YART_ERR_INVALID_ARGUMENT, "yart_wavefront_create: slots out of range (1 .. 2^27)");
-    if ((accel->tri.triaccel.size() && !accel->dSurfRows) || (accel->numSpheres && !accel->dSurfSpheres))
+    if ((accel->numTriangles && !accel->dSurfRows) || (accel->numSpheres && !accel->dSurfSpheres))
         return yart::failStatus(YART_ERR_INVALID_ARGUMENT, "yart_wavefront_create: call yart_accel_set_surface_data first");
     DevGuard guard(accel->device);
     if (!guard.ok) return yart::failStatus(YART_ERR_NO_DEVICE, "hipSetDevice failed");

@@ -29,8 +29,12 @@ public:
     // YART_ERR_TREE_TOO_DEEP: the linear BVH of this scene does not fit the traversal stack (use the host builder).
     int topology(const float* verts, size_t nVerts, const int32_t* tris, size_t nTris, const float* spheres, size_t nSpheres,
                  std::string& err);
-    // dTriAccel: the reference's TriAccel records in leaf order on the device; slotOfInput: host, leaf slot per input triangle.
-    int finish(const void* dTriAccel, const uint32_t* slotOfInput, DeviceWide& out, std::string& err);
+    // dTriAccel: the reference's TriAccel records in leaf order on the device; slotOfInput: leaf slot per input triangle,
+    // a host array or (slotsOnDevice) a device array.
+    int finish(const void* dTriAccel, const uint32_t* slotOfInput, bool slotsOnDevice, DeviceWide& out, std::string& err);
+    // The scene as topology() uploaded it; valid until finish() or destruction (ref_build_dev.hip reads it).
+    const float* deviceVerts() const;
+    const int32_t* deviceTris() const;
 
 private:
     struct State;

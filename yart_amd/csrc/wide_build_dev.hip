@@ -424,6 +424,8 @@ struct DeviceWideBuilder::State {
     int wideDepth = 0;
     const uint32_t* sortedIds = nullptr;
     float* dSpheres = nullptr;
+    float* dVerts = nullptr;
+    int32_t* dTris = nullptr;
     WideNode* wide = nullptr;
     std::chrono::steady_clock::time_point t0;
     double msTopology = 0.0;
@@ -456,6 +458,8 @@ int DeviceWideBuilder::topology(const float* verts, size_t nVerts, const int32_t
     YART_HIP(S.alloc(&primHi, nP));
     YART_HIP(S.alloc(&dBounds, 8));
     st->dSpheres = dSpheres;
+    st->dVerts = dVerts;
+    st->dTris = dTris;
     if (nVerts) YART_HIP(hipMemcpyAsync(dVerts, verts, nVerts * 12, hipMemcpyHostToDevice, nullptr));
     if (nTris) YART_HIP(hipMemcpyAsync(dTris, tris, nTris * 20, hipMemcpyHostToDevice, nullptr));
     if (nSpheres) YART_HIP(hipMemcpyAsync(dSpheres, spheres, nSpheres * 16, hipMemcpyHostToDevice, nullptr));
@@ -565,15 +569,22 @@ int DeviceWideBuilder::topology(const float* verts, size_t nVerts, const int32_t
 }
 
 // Phase 2: what needs the reference's leaf order -- the leaf rows -- and the exact-size result arrays.
-int DeviceWideBuilder::finish(const void* dTriAccel, const uint32_t* slotOfInput, DeviceWide& out, std::string& err)
+const float* DeviceWideBuilder::deviceVerts() const { return state_ ? state_->dVerts : nullptr; }
+const int32_t* DeviceWideBuilder::deviceTris() const { return state_ ? state_->dTris : nullptr; }
+
+int DeviceWideBuilder::finish(const void* dTriAccel, const uint32_t* slotOfInput, bool slotsOnDevice, DeviceWide& out, std::string& err)
 {
     out = DeviceWide{};
     State* st = state_;
     if (!st || st->n < 2) { err = "device builder: finish() without a topology"; return YART_ERR_INVALID_ARGUMENT; }
     const auto tFinish0 = std::chrono::steady_clock::now();
-    uint32_t* dSlot;
-    YART_HIP(st->S.alloc(&dSlot, st->nTris));
-    if (st->nTris) YART_HIP(hipMemcpyAsync(dSlot, slotOfInput, st->nTris * 4, hipMemcpyHostToDevice, nullptr));
+    const uint32_t* dSlot = slotOfInput;
+    if (!slotsOnDevice) {
+        uint32_t* up;
+        YART_HIP(st->S.alloc(&up, st->nTris));
+        if (st->nTris) YART_HIP(hipMemcpyAsync(up, slotOfInput, st->nTris * 4, hipMemcpyHostToDevice, nullptr));
+        dSlot = up;
+    }
     void *nodesOut = nullptr, *rowsA = nullptr, *rowsBC = nullptr;
     hipError_t e = hipMalloc(&nodesOut, st->wideCount * sizeof(WideNode));
     if (e == hipSuccess) e = hipMalloc(&rowsA, st->n * 16);
