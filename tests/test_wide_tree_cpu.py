@@ -191,3 +191,19 @@ def test_scene_with_non_finite_vertices():
     assert (want["prim"] != -1).sum() > 1000
     assert np.array_equal(bits(got["t"]), bits(want["t"]))
     assert (got["prim"] == want["prim"]).mean() >= 0.9999
+
+
+def test_packed_form_round_trip():
+    """yart_build_wide_host hands out the tree after packing it into the 16-byte-unit buffer the kernel reads and
+    unpacking it again (wide_build.h: PackedWide): the grid steps must be ones the packed node can hold (8 exponent
+    + 2 mantissa bits), leaves hold one primitive, and a second build gives the same arrays."""
+    v, t, sph = scenes.random_soup(5000, 400, s=0.05, seed=11)
+    nodes, rows_a, rows_bc, depth = api.build_wide_host(v, t, sph)
+    scale_bits = nodes[:, 3:6]
+    assert (scale_bits & ~np.uint32(0x7FE00000) == 0).all()
+    refs = nodes[:, 12:16]
+    leaf = (refs != NONE) & ((refs & LEAF) != 0)
+    assert (((refs[leaf] >> 27) & 7) == 0).all()
+    assert leaf.sum() == len(t) + len(sph) == len(rows_a)
+    again = api.build_wide_host(v, t, sph, 4)        # max_leaf is accepted and ignored: one primitive per leaf
+    assert again[0].tobytes() == nodes.tobytes() and again[1].tobytes() == rows_a.tobytes() and again[2].tobytes() == rows_bc.tobytes()

@@ -53,6 +53,18 @@ __global__ void __launch_bounds__(256) valu(float* out, uint64_t* cycles, float 
             if (KIND == 20) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
             if (KIND == 21) asm volatile("v_min_f32_e64 %0, %0, %1" : "+v"(a[i]) : "v"(seed));
             if (KIND == 22) asm volatile("v_bfe_u32 %0, %1, 8, 8" : "=v"(a[i]) : "v"(w));
+            // src0 read as the f16 in the low / high half of the register, src1 and src2 as f32
+            if (KIND == 25) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(a[i]) : "v"(w), "v"(seed));
+            if (KIND == 26) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a[i]) : "v"(w), "v"(seed));
+            if (KIND == 27) asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(a[i]) : "v"(w));
+            if (KIND == 28) asm volatile("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(a[i]) : "v"(w));
+            if (KIND == 29) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(seed));
+            if (KIND == 30) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(a[i]) : "v"(seed));
+            if (KIND == 31) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[i]) : "v"(seed));
+            if (KIND == 32) asm volatile("v_lshlrev_b32 %0, 10, %1" : "=v"(a[i]) : "v"(w));
+            if (KIND == 33) asm volatile("v_and_b32 %0, %1, %2" : "=v"(a[i]) : "v"(w), "v"(seed));
+            if (KIND == 34) asm volatile("v_add_u32 %0, %1, %2" : "=v"(a[i]) : "v"(w), "v"(seed));
+            if (KIND == 35) asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(a[i]) : "v"(w), "v"(seed));
         }
         if (KIND == 4) {
 #pragma unroll
@@ -128,6 +140,17 @@ int main()
         run<13>("v_mad_u32_u24", kUnroll, b, out, dCycles, numCUs);
         run<14>("v_lshl_add_u32", kUnroll, b, out, dCycles, numCUs);
         run<16>("v_perm_b32", kUnroll, b, out, dCycles, numCUs);
+        run<25>("v_fma_mix_f32 (f16 lo src0)", kUnroll, b, out, dCycles, numCUs);
+        run<26>("v_fma_mix_f32 (f16 hi src0)", kUnroll, b, out, dCycles, numCUs);
+        run<27>("v_cvt_f32_f16", kUnroll, b, out, dCycles, numCUs);
+        run<28>("v_cvt_f32_f16_sdwa word1", kUnroll, b, out, dCycles, numCUs);
+        run<29>("v_max_f32", kUnroll, b, out, dCycles, numCUs);
+        run<30>("v_pk_max_f16", kUnroll, b, out, dCycles, numCUs);
+        run<31>("v_sub_f32", kUnroll, b, out, dCycles, numCUs);
+        run<32>("v_lshlrev_b32", kUnroll, b, out, dCycles, numCUs);
+        run<33>("v_and_b32", kUnroll, b, out, dCycles, numCUs);
+        run<34>("v_add_u32", kUnroll, b, out, dCycles, numCUs);
+        run<35>("v_add_u32_sdwa byte1", kUnroll, b, out, dCycles, numCUs);
         run<4>("v_pk_fma_f32", kUnroll / 2, b, out, dCycles, numCUs);
         run<23>("v_pk_mul_f32", kUnroll / 2, b, out, dCycles, numCUs);
         run<24>("v_pk_add_f32", kUnroll / 2, b, out, dCycles, numCUs);

@@ -36,15 +36,13 @@ struct YartAccel {
     void* dSphPairs = nullptr;
     void* dSphRecs = nullptr;
     void* dSphIndex = nullptr;
-    void* dWideNodes = nullptr;       // the engine's own 4-wide triangle+sphere tree (wide_build.h)
-    void* dWideRowsA = nullptr;
-    void* dWideRowsBC = nullptr;
+    void* dWideUnits = nullptr;       // the engine's own 4-wide triangle+sphere tree, packed (wide_build.h: PackedWide)
+    size_t wideUnits = 0;
     void* dSurfRows = nullptr;        // hit post-processing (yart_accel_set_surface_data)
     void* dSurfSpheres = nullptr;
     bool hasWide = false;
     bool wideBuiltOnDevice = false;    // YART_BUILD_DEVICE=1 and the device builder took the scene
     double msWideDeviceBuild = 0.0;
-    bool wideMergedRows = false;       // rowsA | rowsBC of a primitive in one 64-byte record (dWideRowsA), dWideRowsBC unused
     size_t wideNodes = 0, widePrims = 0;   // array sizes; the device copy is the only one kept
     int wideDepth = 0;
     size_t deviceBytes = 0;

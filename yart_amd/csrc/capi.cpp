@@ -205,10 +205,8 @@ int runIntersect(YartAccel* a, const Launch& L, const CallScratch* given)
     if (useWide) {
         yart::WideParams W;
         std::memset(&W, 0, sizeof W);
-        W.nodes = static_cast<const float4*>(a->dWideNodes);
-        W.rowsA = static_cast<const float4*>(a->dWideRowsA);
-        if (a->wideMergedRows) { W.rowsBC = W.rowsA + 1; W.rowShift = 2; W.bcStride = 4; }
-        else { W.rowsBC = static_cast<const float4*>(a->dWideRowsBC); W.rowShift = 0; W.bcStride = 2; }
+        W.units = static_cast<const float4*>(a->dWideUnits);
+        W.triaccel = static_cast<const float4*>(a->dTriAccel);
         W.rays = P.rays; W.perm = perm; W.n = n;
         W.hits = P.hits; W.occluded = P.occluded; W.counts = P.counts;
         W.workCounter = slot0;
@@ -347,9 +345,8 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
     const bool useDeviceBuild = wantDeviceBuild && devStatus == YART_OK;
     yart::WideBvh wide;
     if (st == YART_OK && wantWide && !useDeviceBuild) {
-        int maxLeaf = 1;            // measured best on MI355X (tools/exp_wide.py): the box of a single primitive is a
+        const int maxLeaf = 1;      // measured best on MI355X (tools/exp_wide.py): the box of a single primitive is a
                                     // cheaper rejection than its plane row, and rows of different leaves are not tested
-        if (const char* v = std::getenv("YART_WIDE_LEAF")) maxLeaf = std::atoi(v);
         st = yart::buildWideBvh(verts, n_verts, tris, n_tris, a->tri, spheres, n_spheres, maxLeaf, wide, err);
     }
     if (st != YART_OK) { devRef.release(); delete a; return fail(st, err); }
@@ -408,9 +405,9 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
         st = devBuilder.finish(a->dTriAccel, refOnDevice ? static_cast<const uint32_t*>(a->dSlotOfInput) : a->tri.slotOfInput.data(), refOnDevice, dw, err);
         if (st != YART_OK) st = fail(st, err);
         else {
-            a->dWideNodes = dw.nodes; a->dWideRowsA = dw.rowsA; a->dWideRowsBC = dw.rowsBC;
+            a->dWideUnits = dw.units; a->wideUnits = dw.numUnits;
             a->wideNodes = dw.numNodes; a->widePrims = dw.numPrims; a->wideDepth = dw.depth;
-            a->deviceBytes += dw.numNodes * sizeof(yart::WideNode) + dw.numPrims * 48;
+            a->deviceBytes += dw.numUnits * 16;
             a->hasWide = true;
             a->wideBuiltOnDevice = true;
             a->msWideDeviceBuild = dw.msTopology + dw.msFinish;
@@ -419,24 +416,10 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
                                 "reference tree on the host meanwhile: %.1f ms\n", dw.msTopology, dw.numNodes, dw.depth, dw.msFinish, msRefTree);
         }
     } else if (st == YART_OK && wantWide) {
-        st = upload(&a->dWideNodes, wide.nodes.data(), wide.nodes.size() * sizeof(yart::WideNode), a->deviceBytes);
-        const char* merged = std::getenv("YART_WIDE_MERGED_ROWS");
-        a->wideMergedRows = merged && merged[0] == '1';
-        if (a->wideMergedRows) {
-            // one 64-byte record per primitive: first-stage row, the two second-stage rows, 16 bytes unused
-            const size_t np = wide.rowsA.size() / 4;
-            std::vector<float> rec(np * 16, 0.0f);
-            yart::parallelChunks(np, yart::buildThreads(), size_t(1) << 16, [&](size_t b, size_t e) {
-                for (size_t i = b; i < e; ++i) {
-                    std::memcpy(&rec[i * 16], &wide.rowsA[i * 4], 16);
-                    std::memcpy(&rec[i * 16 + 4], &wide.rowsBC[i * 8], 32);
-                }
-            });
-            if (st == YART_OK) st = upload(&a->dWideRowsA, rec.data(), rec.size() * sizeof(float), a->deviceBytes);
-        } else {
-            if (st == YART_OK) st = upload(&a->dWideRowsA, wide.rowsA.data(), wide.rowsA.size() * sizeof(float), a->deviceBytes);
-            if (st == YART_OK) st = upload(&a->dWideRowsBC, wide.rowsBC.data(), wide.rowsBC.size() * sizeof(float), a->deviceBytes);
-        }
+        yart::PackedWide packed;
+        if (!yart::packWide(wide, packed)) { err = "wide BVH does not fit the packed format"; st = fail(YART_ERR_INVALID_ARGUMENT, err); }
+        else st = upload(&a->dWideUnits, packed.words.data(), packed.numUnits * 16, a->deviceBytes);
+        a->wideUnits = packed.numUnits;
         a->hasWide = (st == YART_OK);
         a->wideNodes = wide.nodes.size();
         a->widePrims = wide.rowsA.size() / 4;
@@ -470,9 +453,7 @@ void yart_accel_destroy(YartAccel* a)
             (void)hipFree(kv.second->sortWs);
             delete kv.second;
         }
-        (void)hipFree(a->dWideNodes);
-        (void)hipFree(a->dWideRowsA);
-        (void)hipFree(a->dWideRowsBC);
+        (void)hipFree(a->dWideUnits);
         (void)hipFree(a->dSurfRows);
         (void)hipFree(a->dSurfSpheres);
         for (auto& c : a->stagingFree) {
@@ -743,17 +724,24 @@ int yart_accel_get_wide(const YartAccel* a, void* nodes_out, void* rows_a_out, v
     if (!a) return fail(YART_ERR_INVALID_ARGUMENT, "null argument");
     if (!a->hasWide) return fail(YART_ERR_INVALID_ARGUMENT, "accel was created without the wide tree (YART_NO_WIDE)");
     DeviceGuard guard(a->device);
-    hipError_t e = hipSuccess;
-    if (nodes_out && a->wideNodes) e = hipMemcpy(nodes_out, a->dWideNodes, a->wideNodes * sizeof(yart::WideNode), hipMemcpyDeviceToHost);
-    if (a->wideMergedRows) {
-        const char* rec = static_cast<const char*>(a->dWideRowsA);
-        if (e == hipSuccess && rows_a_out && a->widePrims) e = hipMemcpy2D(rows_a_out, 16, rec, 64, 16, a->widePrims, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && rows_bc_out && a->widePrims) e = hipMemcpy2D(rows_bc_out, 32, rec + 16, 64, 32, a->widePrims, hipMemcpyDeviceToHost);
-    } else {
-        if (e == hipSuccess && rows_a_out && a->widePrims) e = hipMemcpy(rows_a_out, a->dWideRowsA, a->widePrims * 16, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && rows_bc_out && a->widePrims) e = hipMemcpy(rows_bc_out, a->dWideRowsBC, a->widePrims * 32, hipMemcpyDeviceToHost);
+    // the device holds the packed tree only: fetched and unpacked into the node / row arrays (wide_build.h)
+    std::vector<uint32_t> words(a->wideUnits * 4);
+    std::vector<YartTriAccel> fetched;
+    hipError_t e = hipMemcpy(words.data(), a->dWideUnits, a->wideUnits * 16, hipMemcpyDeviceToHost);
+    const YartTriAccel* ta = a->tri.triaccel.data();
+    if (e == hipSuccess && a->refBuiltOnDevice && a->numTriangles) {
+        fetched.resize(a->numTriangles);
+        e = hipMemcpy(fetched.data(), a->dTriAccel, a->numTriangles * sizeof(YartTriAccel), hipMemcpyDeviceToHost);
+        ta = fetched.data();
     }
     if (e != hipSuccess) return failHip(e, "hipMemcpy D2H");
+    yart::WideBvh wide;
+    if (!yart::unpackWide(words.data(), a->wideUnits, ta, a->numTriangles, wide) || wide.nodes.size() != a->wideNodes ||
+        wide.rowsA.size() != a->widePrims * 4)
+        return fail(YART_ERR_HIP, "yart_accel_get_wide: the packed tree on the device is not well formed");
+    if (nodes_out) std::memcpy(nodes_out, wide.nodes.data(), wide.nodes.size() * sizeof(yart::WideNode));
+    if (rows_a_out && a->widePrims) std::memcpy(rows_a_out, wide.rowsA.data(), wide.rowsA.size() * sizeof(float));
+    if (rows_bc_out && a->widePrims) std::memcpy(rows_bc_out, wide.rowsBC.data(), wide.rowsBC.size() * sizeof(float));
     return YART_OK;
 }
 
@@ -781,6 +769,14 @@ int yart_build_wide_host(const float* verts, size_t n_verts, const int32_t* tris
     int st = yart::buildTriangleBvh(verts, n_verts, tris, n_tris, tri, err);
     if (st == YART_OK) st = yart::buildWideBvh(verts, n_verts, tris, n_tris, tri, spheres, n_spheres, max_leaf, wide, err);
     if (st != YART_OK) return fail(st, err);
+    {
+        // what is handed out is what the device would hold: packed (wide_build.h) and unpacked again
+        yart::PackedWide packed;
+        yart::WideBvh back;
+        if (!yart::packWide(wide, packed) || !yart::unpackWide(packed.words.data(), packed.numUnits, tri.triaccel.data(), tri.triaccel.size(), back))
+            return fail(YART_ERR_INVALID_ARGUMENT, "wide BVH does not fit the packed format");
+        wide = std::move(back);
+    }
     if (n_nodes) *n_nodes = wide.nodes.size();
     if (n_prims) *n_prims = wide.rowsA.size() / 4;
     if (depth) *depth = wide.depth;

@@ -42,9 +42,8 @@ __host__ __device__ inline bool regularRay(float ox, float oy, float oz, float t
 }
 
 struct WideParams {
-    const float4* nodes;        // WideNode array viewed as 4 x float4 per node
-    const float4* rowsA;        // first-stage leaf rows, 1 per primitive (wide_build.h)
-    const float4* rowsBC;       // second-stage leaf rows, 2 per primitive
+    const float4* units;        // the packed tree (wide_build.h: PackedWide), 16-byte units
+    const float4* triaccel;     // the reference's leaf-ordered TriAccel records, 3 x float4 each: second-stage rows of a triangle
     const float4* rays;
     const uint32_t* perm;
     uint32_t n;
@@ -57,8 +56,6 @@ struct WideParams {
     uint32_t nodeMin;
     uint32_t maxBlocksPerCU;    // 0 = as many as fit (8)
     uint32_t chunk;             // rays a wave takes from its range counter at a time (multiple of 64)
-    uint32_t rowShift;          // float4 index of primitive p's first-stage row in rowsA = p << rowShift (0: dense rows, 2: one 64-byte record per primitive)
-    uint32_t bcStride;          // float4 index of its second-stage rows in rowsBC = p * bcStride (2: dense, 4: the same 64-byte record)
 };
 
 hipError_t launchTraceWide(const WideParams& P, bool any, bool count, bool persistent, int numCUs,

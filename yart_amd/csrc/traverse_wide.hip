@@ -1,14 +1,15 @@
 // traverse_wide.hip -- the default closest-hit / any-hit kernel: one pass over the engine's own
 // 4-wide BVH of triangles AND spheres (wide_build.h), distance-pruned by the best hit of either kind.
 //
-// Why this shape (measured on MI355X, tools/calib_gather.hip + profiles/): a one-ray-per-lane
-// traversal is bound by how many scattered line requests (~165 G/s from L2, ~50 G/s beyond it) and
-// 16-byte lane requests (~1 per clock per CU) it issues, not by their bytes.  So: one 64-byte node
-// = four quantised child boxes per dependent fetch (4 lane requests, 1 line; the binary tree's
-// sibling pair costs the same for two boxes), half the levels; leaf blocks 64-byte aligned with the
-// rows every primitive's first rejection needs packed first; spheres in the same tree, so neither
-// kind is traversed beyond the other's hit (the reference's order -- all spheres, then the
-// triangle tree, include/scene.h:142-146 -- cannot prune the sphere loop at all).
+// Why this shape (measured on MI355X, tools/calib_gather.hip, tools/calib_valu.hip + profiles/): a one-ray-per-lane
+// traversal pays per wave STEP -- the vector instructions of a node step or a leaf step are issued once for the
+// wave however many of its lanes take part -- and per scattered line request (~165 G/s from L2, ~50 G/s beyond
+// it), not per byte.  So: one node = four quantised child boxes per dependent fetch, three 16-byte requests on one
+// 64-byte line (the binary tree's sibling pair costs four for two boxes), half the levels; the child references
+// are one block address and four byte offsets (wide_build.h: PackedWide); leaf rows packed densely, the rows every
+// primitive's first rejection needs apart from the rest; spheres in the same tree, so neither kind is traversed
+// beyond the other's hit (the reference's order -- all spheres, then the triangle tree, include/scene.h:142-146 --
+// cannot prune the sphere loop at all).
 //
 // Semantics reproduced (per ray, independent of visiting order):
 //   triangles  include/triaccel.h:169-201 on the reference's TriAccel bits; accepted iff
@@ -25,6 +26,7 @@
 // Built with -ffp-contract=off: every tested expression rounds as the reference's C++ does.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdio>
 
 #include "traverse.h"
 #include "wide_build.h"
@@ -42,7 +44,8 @@ constexpr uint32_t kIdle = kWideNone;
 // happened to find the two -- the result for a ray through a shared edge then changed from run to run.
 // The primitive tests keep the exact bound.  (oracle/cpu_ref.cpp traverseWide mirrors it.)
 constexpr float kCullSlack = 1.0f + 0x1p-18f;
-constexpr uint32_t kNeedPop = 0xFFFFFFFEu;       // "take the next stack entry": not a possible leaf reference (first + count <= 2^27 - 1)
+constexpr uint32_t kNeedPop = 0xFFFFFFFDu;       // "take the next stack entry": leaf-like (bit 0), not a possible reference (unit < 2^30 - 2)
+constexpr uint32_t kStepMask = 0x7FE00000u;      // a grid step in the packed node: exponent + two mantissa bits (wide_build.h)
 
 __device__ __forceinline__ uint32_t rangeBegin(uint32_t n, uint32_t i, uint32_t kChunk)
 {
@@ -73,11 +76,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void slab4(const float4& q0, const float4& q1, const float4& q2, const WRay& r,
                                       float bound, float tn[4], bool h[4])
 {
-    const float Ax = (q0.x - r.ox) * r.ix, Bx = q0.w * r.ix;
-    const float Ay = (q0.y - r.oy) * r.iy, By = q1.x * r.iy;
-    const float Az = (q0.z - r.oz) * r.iz, Bz = q1.y * r.iz;
-    const uint32_t lx = __float_as_uint(q1.z), ly = __float_as_uint(q1.w), lz = __float_as_uint(q2.x);
-    const uint32_t hx = __float_as_uint(q2.y), hy = __float_as_uint(q2.z), hz = __float_as_uint(q2.w);
+    const uint32_t steps = __float_as_uint(q0.w);
+    const float sx = __uint_as_float(steps & kStepMask), sy = __uint_as_float((steps << 10) & kStepMask),
+                sz = __uint_as_float((steps << 20) & kStepMask);
+    const float Ax = (q0.x - r.ox) * r.ix, Bx = sx * r.ix;
+    const float Ay = (q0.y - r.oy) * r.iy, By = sy * r.iy;
+    const float Az = (q0.z - r.oz) * r.iz, Bz = sz * r.iz;
+    const uint32_t lx = __float_as_uint(q1.x), ly = __float_as_uint(q1.y), lz = __float_as_uint(q1.z);
+    const uint32_t hx = __float_as_uint(q1.w), hy = __float_as_uint(q2.x), hz = __float_as_uint(q2.y);
     const bool negx = r.ix < 0.0f, negy = r.iy < 0.0f, negz = r.iz < 0.0f;
     const uint32_t nx = negx ? hx : lx, fx = negx ? lx : hx;      // byte c = entry / exit plane of child c
     const uint32_t ny = negy ? hy : ly, fy = negy ? ly : hy;
@@ -137,6 +143,9 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
     int32_t minS = -1, maxL = -1;
     uint32_t occ = 0;
     uint32_t cNodes = 0, cTri = 0, cSph = 0, cStage2 = 0;
+#ifdef YART_STEP_STATS
+    uint32_t stNodeSteps = 0, stNodeLanes = 0, stLeafSteps = 0, stLeafLanes = 0, stIters = 0, stLive = 0;
+#endif
 
     uint32_t chunkNext = 0, chunkEnd = 0;
     bool exhausted = false;
@@ -221,19 +230,24 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
         // leaf is tested in the next leaf phase.  Nodes visited meanwhile are tested against a bound
         // that does not yet know that leaf's hit -- a little extra work for lanes that stay busy.
         for (;;) {
-            if (pend == kIdle && cur != kIdle && cur != kNeedPop && (cur & kWideLeafBit)) { pend = cur; cur = kNeedPop; }
+            if (pend == kIdle && cur != kIdle && cur != kNeedPop && (cur & kPackLeaf)) { pend = cur; cur = kNeedPop; }
             if (cur == kNeedPop) cur = pop();
-            const uint64_t inner = __ballot((cur & kWideLeafBit) == 0);
+            const uint64_t inner = __ballot((cur & kPackLeaf) == 0);
             if (inner == 0) break;
             if (__popcll(inner) < nodeMin && __ballot(pend != kIdle) != 0) break;
-            if ((cur & kWideLeafBit) == 0) {
-                const float4* p = P.nodes + (size_t)cur * 4;
-                const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+#ifdef YART_STEP_STATS
+            ++stNodeSteps; stNodeLanes += __popcll(inner);
+#endif
+            if ((cur & kPackLeaf) == 0) {
+                // three 16-byte requests per visit: the child references are one block address and four byte offsets
+                const float4* p = P.units + (cur >> 2);
+                const float4 q0 = p[0], q1 = p[1], q2 = p[2];
                 const float bound = (ANY ? r.tmax : fminf(tTri, F)) * kCullSlack;
                 float tn[4];
                 uint32_t rf[4];
-                rf[0] = __float_as_uint(q3.x); rf[1] = __float_as_uint(q3.y);
-                rf[2] = __float_as_uint(q3.z); rf[3] = __float_as_uint(q3.w);
+                const uint32_t blk = __float_as_uint(q2.z), offs = __float_as_uint(q2.w);
+                rf[0] = blk + (offs & 255u); rf[1] = blk + ((offs >> 8) & 255u);
+                rf[2] = blk + ((offs >> 16) & 255u); rf[3] = blk + (offs >> 24);
                 bool h[4];
                 slab4(q0, q1, q2, r, bound, tn, h);
                 // an unused slot needs no test of its own: its box is inverted on every axis (qlo 255, qhi 0:
@@ -255,16 +269,17 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
         }
 
         // ------------------------------------------------------------ leaf
+#ifdef YART_STEP_STATS
+        { const uint64_t pm = __ballot(pend != kIdle); if (pm) { ++stLeafSteps; stLeafLanes += __popcll(pm); } ++stIters; stLive += __popcll(__ballot(live)); }
+#endif
         if (pend != kIdle) {
             const uint32_t leaf = pend;
             pend = kIdle;
-            const uint32_t cnt = ((leaf >> 27) & 7u) + 1u;
-            const uint32_t first = leaf & 0x07FFFFFFu;
-            const float4* blk = P.rowsA + ((size_t)first << P.rowShift);
+            const float4* row = P.units + (leaf >> 2);          // one primitive per leaf
             bool stop = false;
-            if ((leaf & kWideSphereBit) == 0) {
-                for (uint32_t i = 0; i < cnt; ++i) {
-                    const float4 A = blk[(size_t)i << P.rowShift];
+            if ((leaf & kPackSphere) == 0) {
+                do {
+                    const float4 A = row[0];
                     if (COUNT) ++cTri;
                     // include/triaccel.h:169-201
                     const uint32_t kw = __float_as_uint(A.w);
@@ -281,40 +296,42 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
                     // slot wins there.  An exact tie therefore goes to the lower slot here, whatever
                     // order this tree finds them in.
                     const bool tie = !ANY && t == tTri && (int32_t)(kw >> 2) < primTri;
-                    if (!((bound > t || tie) && t > 0.0001f)) continue;
-                    const float4 B = P.rowsBC[(size_t)(first + i) * P.bcStride], C = P.rowsBC[(size_t)(first + i) * P.bcStride + 1];
+                    if (!((bound > t || tie) && t > 0.0001f)) break;
+                    // second stage: rows b and c of the reference's TriAccel record of this slot
+                    const float4* ta = P.triaccel + (size_t)(kw >> 2) * 3;
+                    const float4 B = ta[1], C = ta[2];
                     if (COUNT) ++cStage2;
                     const float phu = ou + t * du;
                     const float phv = ov + t * dv;
                     const float lambda = phu * B.x + phv * B.y + B.z;
-                    if (lambda < 0.0f) continue;
+                    if (lambda < 0.0f) break;
                     const float mue = phu * C.x + phv * C.y + C.z;
-                    if (mue < 0.0f) continue;
-                    if (lambda + mue > 1.0f) continue;
+                    if (mue < 0.0f) break;
+                    if (lambda + mue > 1.0f) break;
                     if (ANY) { occ = 1; stop = true; break; }
                     tTri = t; hv = lambda; hu = mue;       // include/triaccel.h:194-196
                     primTri = (int32_t)(kw >> 2);
-                }
+                } while (false);
             } else {
-                for (uint32_t i = 0; i < cnt; ++i) {
-                    const float4 S = blk[(size_t)i << P.rowShift];
+                do {
+                    const float4 S = row[0];
                     if (COUNT) ++cSph;
                     // include/sphere.h:63-97
                     const float opx = S.x - r.ox, opy = S.y - r.oy, opz = S.z - r.oz;
                     const double b = (double)(opx * r.dx + opy * r.dy + opz * r.dz);
                     double det = b * b - (double)(opx * opx + opy * opy + opz * opz) + (double)(S.w * S.w);
-                    if (det < 0) continue;
+                    if (det < 0) break;
                     det = sqrt(det);
                     const double eps = (double)1e-4f;
                     double t = b - det;
                     if (!(t > eps)) t = b + det;
-                    if (!(t > eps && t < (double)r.tmax)) continue;
+                    if (!(t > eps && t < (double)r.tmax)) break;
                     if (ANY) { occ = 1; stop = true; break; }
                     const float f = (float)t;
                     // a sphere whose float t lies beyond the best triangle cannot be the result
                     // (the triangle is strictly closer); beyond the best sphere neither
-                    if (f > fminf(tTri, F)) continue;
-                    const int32_t idx = (int32_t)__float_as_uint(P.rowsBC[(size_t)(first + i) * P.bcStride].x);
+                    if (f > fminf(tTri, F)) break;
+                    const int32_t idx = (int32_t)__float_as_uint(row[1].x);
                     if (COUNT) ++cStage2;
                     const bool below = t < (double)f;
                     if (minS < 0 || f < F) { F = f; minS = idx; maxL = below ? idx : -1; }
@@ -322,7 +339,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
                         minS = (idx < minS) ? idx : minS;
                         if (below && idx > maxL) maxL = idx;
                     }
-                }
+                } while (false);
             }
             if (stop) { cur = kIdle; sp = 0; }
         }
@@ -347,6 +364,14 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
             }
         }
     }
+#ifdef YART_STEP_STATS
+    // experiment builds only (make EXTRA=-DYART_STEP_STATS): how full the waves are in the two phases
+    if (lane == 0) {
+        atomicAdd(P.workCounter + 2, stNodeSteps); atomicAdd(P.workCounter + 3, stNodeLanes >> 6);
+        atomicAdd(P.workCounter + 4, stLeafSteps); atomicAdd(P.workCounter + 5, stLeafLanes >> 6);
+        atomicAdd(P.workCounter + 6, stIters); atomicAdd(P.workCounter + 7, stLive >> 6);
+    }
+#endif
 }
 
 template <bool ANY, bool COUNT>
@@ -367,6 +392,12 @@ hipError_t launchW(const WideParams& P, bool persistent, int numCUs, hipStream_t
         const uint32_t needBlocks = (need + 3) / 4;
         if (grid > needBlocks) grid = needBlocks;
         hipLaunchKernelGGL((traceWide<ANY, COUNT, true>), dim3(grid), dim3(kBlock), 0, stream, P);
+#ifdef YART_STEP_STATS
+        uint32_t st[8];
+        if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(st, P.workCounter, sizeof st, hipMemcpyDeviceToHost) == hipSuccess && P.n > 1000000)
+            fprintf(stderr, "step stats (%u rays, any=%d): node steps %u, mean lanes %.1f; leaf steps %u, mean lanes %.1f; outer iterations %u, mean live lanes %.1f\n",
+                    P.n, (int)ANY, st[2], 64.0 * st[3] / (st[2] ? st[2] : 1), st[4], 64.0 * st[5] / (st[4] ? st[4] : 1), st[6], 64.0 * st[7] / (st[6] ? st[6] : 1));
+#endif
     } else {
         const uint32_t grid = (P.n + kBlock - 1) / kBlock;
         hipLaunchKernelGGL((traceWide<ANY, COUNT, false>), dim3(grid), dim3(kBlock), 0, stream, P);

@@ -459,6 +459,7 @@ private:
             const float origin = all.lo[a];
             float scale = (all.hi[a] - all.lo[a]) / 255.0f;
             if (!(scale > 0.0f) || !(scale < std::numeric_limits<float>::infinity())) scale = 1.0f;   // flat or unbounded axis
+            scale = packedStep(scale);                   // the step the packed node can hold (wide_build.h)
             for (;;) {
                 bool ok = true;
                 for (int i = 0; i < n && ok; ++i) {
@@ -472,7 +473,7 @@ private:
                     w.qhi[a][i] = static_cast<uint8_t>(qh);
                 }
                 if (ok) break;
-                scale = std::nextafter(scale * 1.000001f, std::numeric_limits<float>::infinity());
+                scale = packedStep(std::nextafter(scale, std::numeric_limits<float>::infinity()));
             }
             w.origin[a] = origin;
             w.scale[a] = scale;
@@ -659,15 +660,175 @@ void relayout(WideBvh& bvh, int mode)
     bvh.nodes.swap(out);
 }
 
+uint32_t floatBits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+constexpr uint32_t kStepMask = 0x7FE00000u;             // exponent + two mantissa bits
+
 } // namespace
+
+float packedStep(float s)
+{
+    uint32_t u = floatBits(s);
+    if (u & ~kStepMask) u = (u & kStepMask) + 0x00200000u;          // round up; a mantissa carry bumps the exponent
+    if (u < 0x00800000u) u = 0x00800000u;                            // no denormal steps
+    if (u >= 0x7F800000u) u = 0x7F600000u;                           // nor infinite ones: the largest step (1.75 * 2^127)
+    return bitsFloat(u);
+}
+
+bool packWide(const WideBvh& bvh, PackedWide& out)
+{
+    const size_t n = bvh.nodes.size();
+    out.words.clear();
+    out.numUnits = 0;
+    if (n == 0) return false;
+    // Children blocks one after the other, in node order, in two regions: blocks with interior children (64-byte
+    // aligned; the leaf rows of such a node follow its interior children, padded to 64 bytes) behind the root, then
+    // the blocks of the nodes that have leaf children only -- nothing but rows, packed densely, so that the rows
+    // of neighbouring leaves share cache lines.
+    std::vector<uint32_t> block(n), unitOf(n, 0u);
+    size_t totalNodes = 4, totalRows = 0;
+    for (size_t i = 0; i < n; ++i) {
+        size_t interior = 0, leafUnits = 0;
+        for (const uint32_t r : bvh.nodes[i].ref) {
+            if (r == kWideNone) continue;
+            if (!(r & kWideLeafBit)) ++interior;
+            else {
+                if ((r >> 27) & 7u) return false;                    // single-primitive leaves only
+                leafUnits += (r & kWideSphereBit) ? 2 : 1;
+            }
+        }
+        if (interior) {
+            block[i] = static_cast<uint32_t>(totalNodes);
+            totalNodes += 4 * interior + (leafUnits + 3) / 4 * 4;
+        } else {
+            block[i] = static_cast<uint32_t>(totalRows) | 0x80000000u;       // rebased below
+            totalRows += leafUnits;
+        }
+        if (totalNodes + totalRows > kPackMaxUnits) return false;
+    }
+    for (size_t i = 0; i < n; ++i)
+        if (block[i] & 0x80000000u) block[i] = static_cast<uint32_t>(totalNodes + (block[i] & 0x7FFFFFFFu));
+    const size_t total = totalNodes + totalRows;
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t j = 0;
+        for (const uint32_t r : bvh.nodes[i].ref)
+            if (r != kWideNone && !(r & kWideLeafBit)) {
+                if (r >= n) return false;
+                unitOf[r] = block[i] + 4 * j++;
+            }
+    }
+    out.numUnits = total;
+    out.words.assign(total * 4, 0u);
+    std::atomic<bool> ok{ true };
+    parallelChunks(n, buildThreads(), size_t(1) << 14, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            const WideNode& w = bvh.nodes[i];
+            uint32_t* u = &out.words[static_cast<size_t>(unitOf[i]) * 4];
+            uint32_t steps = 0;
+            for (int a = 0; a < 3; ++a) {
+                u[a] = floatBits(w.origin[a]);
+                const uint32_t sb = floatBits(w.scale[a]);
+                if (sb & ~kStepMask) ok = false;                     // not a step of the packed format
+                steps |= sb >> (10 * a);
+            }
+            u[3] = steps;
+            for (int a = 0; a < 3; ++a) std::memcpy(&u[4 + a], w.qlo[a], 4);
+            for (int a = 0; a < 3; ++a) std::memcpy(&u[7 + a], w.qhi[a], 4);
+            uint32_t interior = 0;
+            for (const uint32_t r : w.ref) interior += (r != kWideNone && !(r & kWideLeafBit)) ? 1u : 0u;
+            uint32_t offs = 0, nextInterior = 0, nextLeaf = 4 * interior;
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t r = w.ref[c];
+                if (r == kWideNone) continue;
+                if (!(r & kWideLeafBit)) {
+                    offs |= ((4u * nextInterior++) << 2) << (8 * c);
+                    continue;
+                }
+                const bool sph = (r & kWideSphereBit) != 0;
+                const size_t first = r & 0x07FFFFFFu;
+                offs |= ((nextLeaf << 2) | kPackLeaf | (sph ? kPackSphere : 0u)) << (8 * c);
+                uint32_t* row = &out.words[(static_cast<size_t>(block[i]) + nextLeaf) * 4];
+                std::memcpy(row, &bvh.rowsA[first * 4], 16);
+                if (sph) std::memcpy(row + 4, &bvh.rowsBC[first * 8], 4);      // the sphere's number
+                nextLeaf += sph ? 2u : 1u;
+            }
+            u[10] = block[i] << 2;
+            u[11] = offs;
+        }
+    });
+    return ok;
+}
+
+bool unpackWide(const uint32_t* words, size_t numUnits, const YartTriAccel* triaccel, size_t nTriangles, WideBvh& out)
+{
+    out = WideBvh{};
+    if (numUnits < 4) return false;
+    std::vector<uint32_t> level{ 0u }, next;             // unit indices of the nodes of one level
+    std::vector<uint32_t> unitOfNode{ 0u };
+    out.nodes.emplace_back();
+    size_t done = 0;
+    while (!level.empty()) {
+        ++out.depth;
+        next.clear();
+        for (const uint32_t unit : level) {
+            if (static_cast<size_t>(unit) + 4 > numUnits) return false;
+            const uint32_t* u = words + static_cast<size_t>(unit) * 4;
+            WideNode w;
+            std::memset(&w, 0, sizeof w);
+            for (int a = 0; a < 3; ++a) {
+                w.origin[a] = bitsFloat(u[a]);
+                w.scale[a] = bitsFloat((u[3] << (10 * a)) & kStepMask);
+                std::memcpy(w.qlo[a], &u[4 + a], 4);
+                std::memcpy(w.qhi[a], &u[7 + a], 4);
+            }
+            const size_t blockUnit = u[10] >> 2;
+            for (int c = 0; c < 4; ++c) {
+                w.ref[c] = kWideNone;
+                if (w.qlo[0][c] > w.qhi[0][c]) continue;             // unused slot: inverted box
+                const uint32_t ob = (u[11] >> (8 * c)) & 255u;
+                const size_t child = blockUnit + (ob >> 2);
+                if (!(ob & kPackLeaf)) {
+                    if (out.nodes.size() + next.size() >= (size_t(1) << 31)) return false;
+                    w.ref[c] = static_cast<uint32_t>(unitOfNode.size());
+                    unitOfNode.push_back(static_cast<uint32_t>(child));
+                    next.push_back(static_cast<uint32_t>(child));
+                    continue;
+                }
+                const bool sph = (ob & kPackSphere) != 0;
+                if (child + (sph ? 2 : 1) > numUnits) return false;
+                const uint32_t* row = words + child * 4;
+                const size_t first = out.rowsA.size() / 4;
+                if (first > kWideMaxPrims) return false;
+                out.rowsA.resize((first + 1) * 4);
+                out.rowsBC.resize((first + 1) * 8, 0.0f);
+                std::memcpy(&out.rowsA[first * 4], row, 16);
+                if (sph) std::memcpy(&out.rowsBC[first * 8], row + 4, 4);
+                else {
+                    const size_t slot = row[3] >> 2;
+                    if (slot >= nTriangles) return false;
+                    const YartTriAccel& ta = triaccel[slot];
+                    float* B = &out.rowsBC[first * 8];
+                    B[0] = ta.b_u; B[1] = ta.b_v; B[2] = ta.b_d;
+                    B[4] = ta.c_u; B[5] = ta.c_v; B[6] = ta.c_d;
+                }
+                w.ref[c] = kWideLeafBit | (sph ? kWideSphereBit : 0u) | static_cast<uint32_t>(first);
+                ++out.numLeaves;
+            }
+            if (done >= out.nodes.size()) return false;
+            out.nodes[done++] = w;
+        }
+        out.nodes.resize(unitOfNode.size());
+        level.swap(next);
+        if (out.depth > kWideStack) return false;
+    }
+    return done == out.nodes.size();
+}
 
 int buildWideBvh(const float* verts, size_t nVerts, const int32_t* tris, size_t nTris,
                  const TriangleBvh& tri, const float* spheres, size_t nSpheres,
                  int maxLeaf, WideBvh& out, std::string& err)
 {
     (void)nVerts;
-    if (maxLeaf < 1) maxLeaf = 1;
-    if (maxLeaf > kWideMaxLeaf) maxLeaf = kWideMaxLeaf;
+    maxLeaf = 1;            // one primitive per leaf: what the packed format holds (wide_build.h)
     if (nTris >= (1u << 30) || nSpheres >= (1u << 30)) {
         err = "wide BVH: more than 2^30 primitives of one kind";
         return YART_ERR_INVALID_ARGUMENT;

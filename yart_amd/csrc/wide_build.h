@@ -22,9 +22,10 @@
 
 namespace yart {
 
-// One node = one 64-byte line: four child boxes quantised to 8 bits per plane on the node's own
-// grid (origin + q * scale per axis; lower planes rounded down, upper planes up, so a quantised box
-// always contains the exact one), SoA by plane so a plane of all four children is one dword.
+// The BUILDERS' form of a node (the kernel reads the packed form further down; yart_accel_get_wide hands this one
+// out): four child boxes quantised to 8 bits per plane on the node's own grid (origin + q * scale per axis;
+// lower planes rounded down, upper planes up, so a quantised box always contains the exact one; scale is a step
+// the packed form can hold, packedStep()), SoA by plane so a plane of all four children is one dword.
 //   dwords 0-2  origin x, y, z (float)          dwords 3-5   scale x, y, z (float)
 //   dword  6-8  lower planes x, y, z, byte c = child c      dwords 9-11  upper planes x, y, z
 //   dwords 12-15 child refs
@@ -66,8 +67,46 @@ struct WideBvh {
     size_t numLeaves = 0;
 };
 
+// ---------------------------------------------------------------------------------------------------------
+// What the traversal kernel reads: the same tree PACKED into one buffer of 16-byte units, so that a node visit
+// is THREE 16-byte lane requests instead of four (the request count, not the byte count, is what the kernel
+// pays for: profiles/r02_ab_extraload.txt).  The children of a node form one block of consecutive units --
+// its interior children first (64 bytes = 4 units each, 64-byte aligned), then its leaf children's rows --
+// so the four child references shrink to one block address and four one-byte offsets; the grid steps are
+// kept to 10 bits each (8 exponent + 2 mantissa bits, rounded up).
+//
+//   node, 4 units (the fourth unused):
+//     unit 0   origin x, y, z (float) | steps: bits 30..21 x, 20..11 y, 10..1 z = bits 30..21 of the float step
+//     unit 1   lower planes x, y, z (byte c = child c) | upper planes x
+//     unit 2   upper planes y, z | block: (unit index of the children block) << 2 | offsets: byte c = (unit offset of
+//              child c inside the block) << 2 | class of child c
+//   reference = (unit index << 2) | class;  class bit 0 = leaf, bit 1 = sphere;  the root node is reference 0
+//   triangle leaf, 1 unit:  n_u, n_v, n_d, bits(k | slot << 2)   -- second stage: rows b and c of TriAccel record `slot`
+//                           of the reference's leaf-ordered array (the accel's dTriAccel), nothing is duplicated
+//   sphere leaf, 2 units:   cx, cy, cz, radius | sphere number, 0, 0, 0
+// Leaves hold one primitive.  An unused child slot keeps its inverted box (never entered); its offset byte is 0.
+constexpr uint32_t kPackLeaf = 1u, kPackSphere = 2u;
+constexpr size_t kPackMaxUnits = (size_t(1) << 30) - 2;
+
+struct PackedWide {
+    std::vector<uint32_t> words;        // 4 per unit
+    size_t numUnits = 0;
+};
+
+// The 10-bit step the packed node stores for a float step `s` (> 0, finite): the smallest representable value >= s,
+// as the float it decodes to.  The builders quantise child boxes on THIS step, so WideNode::scale holds it too.
+float packedStep(float s);
+
+// WideBvh (single-primitive leaves) -> packed buffer.  Nodes keep their order: the block of node i's children
+// follows the block of node i - 1's.  false: the tree does not fit the format (too many units).
+bool packWide(const WideBvh& bvh, PackedWide& out);
+// The inverse, for inspection and tests (yart_accel_get_wide): nodes numbered in the order a breadth-first walk
+// from the root meets them, rows in the order it meets their leaves.  `triaccel`: the reference's leaf-ordered records.
+bool unpackWide(const uint32_t* words, size_t numUnits, const YartTriAccel* triaccel, size_t nTriangles, WideBvh& out);
+
 // `tri` supplies the reference-order TriAccel records and, per input triangle, its leaf slot.
-// maxLeaf in 1..8.  Returns YART_OK or an error status with `err` set.
+// maxLeaf is kept for the callers that pass it; leaves hold one primitive (the packed format has no count, and
+// larger leaves measured slower on MI355X: tools/exp_wide.py).  Returns YART_OK or an error status with `err` set.
 int buildWideBvh(const float* verts, size_t nVerts, const int32_t* tris, size_t nTris,
                  const TriangleBvh& tri, const float* spheres, size_t nSpheres,
                  int maxLeaf, WideBvh& out, std::string& err);

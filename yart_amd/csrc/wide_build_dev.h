@@ -9,9 +9,8 @@
 namespace yart {
 
 struct DeviceWide {
-    void* nodes = nullptr;          // device arrays, owned by the caller after finish(): hipFree
-    void* rowsA = nullptr;
-    void* rowsBC = nullptr;
+    void* units = nullptr;          // the packed tree (wide_build.h: PackedWide) on the device, owned by the caller after finish(): hipFree
+    size_t numUnits = 0;
     size_t numNodes = 0, numPrims = 0;
     int depth = 0;
     double msBuild = 0.0;           // wall time from the start of topology() to the end of finish()

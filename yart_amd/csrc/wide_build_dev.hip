@@ -279,6 +279,16 @@ __device__ inline void gatherKids(const uint32_t* left, const uint32_t* right, c
     }
 }
 
+// wide_build.cpp packedStep: the smallest step the packed node can hold (8 exponent + 2 mantissa bits) that is >= s
+__device__ inline float packedStepDev(float s)
+{
+    uint32_t u = __float_as_uint(s);
+    if (u & ~0x7FE00000u) u = (u & 0x7FE00000u) + 0x00200000u;
+    if (u < 0x00800000u) u = 0x00800000u;
+    if (u >= 0x7F800000u) u = 0x7F600000u;
+    return __uint_as_float(u);
+}
+
 // Quantise up to four child boxes on the grid of their union (wide_build.cpp setChildren): containment is
 // decided in double on the float values the traversal kernel will read.
 __device__ inline void setChildren(WideNode& w, const float4* lo, const float4* hi, const uint32_t* refs, int n)
@@ -303,6 +313,7 @@ __device__ inline void setChildren(WideNode& w, const float4* lo, const float4* 
         const float origin = allLo;
         float scale = (allHi - allLo) / 255.0f;
         if (!(scale > 0.0f) || !(scale < __builtin_inff())) scale = 1.0f;      // flat or unbounded axis
+        scale = packedStepDev(scale);
         for (int guard = 0; guard < 64; ++guard) {
             bool ok = true;
             for (int i = 0; i < n && ok; ++i) {
@@ -316,7 +327,7 @@ __device__ inline void setChildren(WideNode& w, const float4* lo, const float4* 
                 w.qhi[a][i] = (uint8_t)qh;
             }
             if (ok) break;
-            scale = nextafterf(scale * 1.000001f, __builtin_inff());
+            scale = packedStepDev(nextafterf(scale, __builtin_inff()));
         }
         w.origin[a] = origin;
         w.scale[a] = scale;
@@ -379,26 +390,122 @@ __global__ void __launch_bounds__(256) emitLevel(const QueueEntry* __restrict__ 
     out[e.wide] = w;
 }
 
-// leaf rows in sorted order: the reference's TriAccel bits of the triangle's slot / the sphere record
+// ---- packing (wide_build.h: PackedWide).  The emitted nodes are in breadth-first order with the interior children
+// of a node side by side; the block of node i's children follows the block of node i - 1's.
+__device__ inline void childCounts(const WideNode& w, uint32_t& interior, uint32_t& leafUnits)
+{
+    interior = 0; leafUnits = 0;
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t r = w.ref[c];
+        if (r == kWideNone) continue;
+        if (!(r & kWideLeafBit)) ++interior;
+        else leafUnits += (r & kWideSphereBit) ? 2u : 1u;
+    }
+}
+
+// Two regions (wide_build.cpp packWide): blocks with interior children, 64-byte aligned, and behind them the rows of
+// the nodes with leaf children only.  Those rows keep the Morton order of their primitives (the leaves below one node
+// are neighbours in that order), so neighbours in space share cache lines; the rows of leaves that live in a block of
+// the first region leave their units of the second unused.
+__global__ void __launch_bounds__(256) packSizes(const WideNode* __restrict__ nodes, uint32_t n, uint32_t* __restrict__ sizesN,
+                                                 uint32_t* __restrict__ firstPos)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const WideNode w = nodes[i];
+    uint32_t interior, leafUnits;
+    childCounts(w, interior, leafUnits);
+    sizesN[i] = interior ? 4u * interior + (leafUnits + 3u) / 4u * 4u : 0u;
+    uint32_t first = 0;
+    for (int c = 3; c >= 0; --c)
+        if (w.ref[c] != kWideNone && (w.ref[c] & kWideLeafBit)) first = w.ref[c] & 0x07FFFFFFu;
+    firstPos[i] = first;
+}
+
+__global__ void __launch_bounds__(256) rowUnits(const uint32_t* __restrict__ sortedIds, uint32_t n, uint32_t nTris, uint32_t* __restrict__ units)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r < n) units[r] = sortedIds[r] < nTris ? 1u : 2u;
+}
+
+// block[i]: unit index of node i's children block
+__global__ void __launch_bounds__(256) packBlocks(const uint32_t* __restrict__ sizesN, const uint32_t* __restrict__ sumN,
+                                                  const uint32_t* __restrict__ firstPos, const uint32_t* __restrict__ rowSum, uint32_t n,
+                                                  uint32_t rowsBase, uint32_t* __restrict__ block)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    block[i] = sizesN[i] ? 4u + sumN[i] : rowsBase + rowSum[firstPos[i]];
+}
+
+// where every node and every leaf row goes
+__global__ void __launch_bounds__(256) packAssign(const WideNode* __restrict__ nodes, uint32_t n, const uint32_t* __restrict__ block,
+                                                  uint32_t* __restrict__ unitOf, uint32_t* __restrict__ leafUnit)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const WideNode w = nodes[i];
+    uint32_t interior, leafUnits;
+    childCounts(w, interior, leafUnits);
+    const uint32_t base = block[i];
+    uint32_t nextInterior = 0, nextLeaf = 4u * interior;
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t r = w.ref[c];
+        if (r == kWideNone) continue;
+        if (!(r & kWideLeafBit)) { unitOf[r] = base + 4u * nextInterior++; continue; }
+        leafUnit[r & 0x07FFFFFFu] = base + nextLeaf;
+        nextLeaf += (r & kWideSphereBit) ? 2u : 1u;
+    }
+    if (i == 0) unitOf[0] = 0u;
+}
+
+__global__ void __launch_bounds__(256) packNodes(const WideNode* __restrict__ nodes, uint32_t n, const uint32_t* __restrict__ block,
+                                                 const uint32_t* __restrict__ unitOf, uint4* __restrict__ units)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const WideNode w = nodes[i];
+    uint32_t interior, leafUnits;
+    childCounts(w, interior, leafUnits);
+    uint32_t steps = 0, lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) {
+        steps |= (__float_as_uint(w.scale[a]) & 0x7FE00000u) >> (10 * a);
+        lo[a] = (uint32_t)w.qlo[a][0] | ((uint32_t)w.qlo[a][1] << 8) | ((uint32_t)w.qlo[a][2] << 16) | ((uint32_t)w.qlo[a][3] << 24);
+        hi[a] = (uint32_t)w.qhi[a][0] | ((uint32_t)w.qhi[a][1] << 8) | ((uint32_t)w.qhi[a][2] << 16) | ((uint32_t)w.qhi[a][3] << 24);
+    }
+    uint32_t offs = 0, nextInterior = 0, nextLeaf = 4u * interior;
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t r = w.ref[c];
+        if (r == kWideNone) continue;
+        if (!(r & kWideLeafBit)) { offs |= ((4u * nextInterior++) << 2) << (8 * c); continue; }
+        const bool sph = (r & kWideSphereBit) != 0;
+        offs |= ((nextLeaf << 2) | kPackLeaf | (sph ? kPackSphere : 0u)) << (8 * c);
+        nextLeaf += sph ? 2u : 1u;
+    }
+    uint4* u = units + unitOf[i];
+    u[0] = make_uint4(__float_as_uint(w.origin[0]), __float_as_uint(w.origin[1]), __float_as_uint(w.origin[2]), steps);
+    u[1] = make_uint4(lo[0], lo[1], lo[2], hi[0]);
+    u[2] = make_uint4(hi[1], hi[2], block[i] << 2, offs);
+}
+
+// leaf rows: the reference's TriAccel bits of the triangle's slot / the sphere record, at the unit packAssign chose
 __global__ void __launch_bounds__(256) leafRows(const uint32_t* __restrict__ sortedIds, uint32_t n, uint32_t nTris,
                                                 const uint32_t* __restrict__ slotOfInput, const float4* __restrict__ triaccel,
-                                                const float4* __restrict__ spheres, float4* __restrict__ rowsA, float4* __restrict__ rowsBC)
+                                                const float4* __restrict__ spheres, const uint32_t* __restrict__ leafUnit, float4* __restrict__ units)
 {
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
     if (r >= n) return;
     const uint32_t p = sortedIds[r];
+    float4* row = units + leafUnit[r];
     if (p < nTris) {
         const uint32_t slot = slotOfInput[p];
-        const float4 a = triaccel[(size_t)slot * 3 + 0], b = triaccel[(size_t)slot * 3 + 1], c = triaccel[(size_t)slot * 3 + 2];
+        const float4 a = triaccel[(size_t)slot * 3 + 0];
         const uint32_t k = __float_as_uint(a.w);                        // TriAccel::k (0..2)
-        rowsA[r] = make_float4(a.x, a.y, a.z, __uint_as_float((k & 3u) | (slot << 2)));
-        rowsBC[(size_t)r * 2 + 0] = make_float4(b.x, b.y, b.z, 0.0f);
-        rowsBC[(size_t)r * 2 + 1] = make_float4(c.x, c.y, c.z, 0.0f);
+        row[0] = make_float4(a.x, a.y, a.z, __uint_as_float((k & 3u) | (slot << 2)));
     } else {
         const uint32_t s = p - nTris;
-        rowsA[r] = spheres[s];
-        rowsBC[(size_t)r * 2 + 0] = make_float4(__uint_as_float(s), 0.0f, 0.0f, 0.0f);
-        rowsBC[(size_t)r * 2 + 1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        row[0] = spheres[s];
+        row[1] = make_float4(__uint_as_float(s), 0.0f, 0.0f, 0.0f);
     }
 }
 
@@ -585,24 +692,54 @@ int DeviceWideBuilder::finish(const void* dTriAccel, const uint32_t* slotOfInput
         if (st->nTris) YART_HIP(hipMemcpyAsync(up, slotOfInput, st->nTris * 4, hipMemcpyHostToDevice, nullptr));
         dSlot = up;
     }
-    void *nodesOut = nullptr, *rowsA = nullptr, *rowsBC = nullptr;
-    hipError_t e = hipMalloc(&nodesOut, st->wideCount * sizeof(WideNode));
-    if (e == hipSuccess) e = hipMalloc(&rowsA, st->n * 16);
-    if (e == hipSuccess) e = hipMalloc(&rowsBC, st->n * 32);
-    if (e == hipSuccess) e = hipMemcpyAsync(nodesOut, st->wide, st->wideCount * sizeof(WideNode), hipMemcpyDeviceToDevice, nullptr);
+    // pack: block sizes, their running sum, the place of every node and leaf row, the packed units
+    const uint32_t nNodes = static_cast<uint32_t>(st->wideCount), nPrims = static_cast<uint32_t>(st->n);
+    uint32_t *sizesN, *sumN, *firstPos, *rowSize, *rowSum, *block, *unitOf, *leafUnit;
+    YART_HIP(st->S.alloc(&sizesN, nNodes));
+    YART_HIP(st->S.alloc(&sumN, nNodes));
+    YART_HIP(st->S.alloc(&firstPos, nNodes));
+    YART_HIP(st->S.alloc(&rowSize, nPrims));
+    YART_HIP(st->S.alloc(&rowSum, nPrims));
+    YART_HIP(st->S.alloc(&block, nNodes));
+    YART_HIP(st->S.alloc(&unitOf, nNodes));
+    YART_HIP(st->S.alloc(&leafUnit, nPrims));
+    hipLaunchKernelGGL(packSizes, dim3(blocks(nNodes)), dim3(256), 0, nullptr, st->wide, nNodes, sizesN, firstPos);
+    hipLaunchKernelGGL(rowUnits, dim3(blocks(nPrims)), dim3(256), 0, nullptr, st->sortedIds, nPrims, (uint32_t)st->nTris, rowSize);
+    YART_HIP(hipGetLastError());
+    size_t scanBytes = 0, scanBytes2 = 0;
+    YART_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scanBytes, sizesN, sumN, (int)nNodes, nullptr));
+    YART_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scanBytes2, rowSize, rowSum, (int)nPrims, nullptr));
+    scanBytes = std::max(scanBytes, scanBytes2);
+    char* scanTemp;
+    YART_HIP(st->S.alloc(&scanTemp, scanBytes));
+    YART_HIP(hipcub::DeviceScan::ExclusiveSum(scanTemp, scanBytes, sizesN, sumN, (int)nNodes, nullptr));
+    YART_HIP(hipcub::DeviceScan::ExclusiveSum(scanTemp, scanBytes, rowSize, rowSum, (int)nPrims, nullptr));
+    uint32_t last[4];
+    YART_HIP(hipMemcpy(&last[0], sumN + (nNodes - 1), 4, hipMemcpyDeviceToHost));
+    YART_HIP(hipMemcpy(&last[1], sizesN + (nNodes - 1), 4, hipMemcpyDeviceToHost));
+    YART_HIP(hipMemcpy(&last[2], rowSum + (nPrims - 1), 4, hipMemcpyDeviceToHost));
+    YART_HIP(hipMemcpy(&last[3], rowSize + (nPrims - 1), 4, hipMemcpyDeviceToHost));
+    const size_t rowsBase = size_t(4) + last[0] + last[1];
+    const size_t numUnits = rowsBase + last[2] + last[3];
+    if (numUnits > kPackMaxUnits) { err = "device builder: tree too large for the packed format"; return YART_ERR_INVALID_ARGUMENT; }
+    void* units = nullptr;
+    hipError_t e = hipMalloc(&units, numUnits * 16);
+    if (e == hipSuccess) e = hipMemsetAsync(units, 0, numUnits * 16, nullptr);
     if (e == hipSuccess) {
+        hipLaunchKernelGGL(packBlocks, dim3(blocks(nNodes)), dim3(256), 0, nullptr, sizesN, sumN, firstPos, rowSum, nNodes, (uint32_t)rowsBase, block);
+        hipLaunchKernelGGL(packAssign, dim3(blocks(nNodes)), dim3(256), 0, nullptr, st->wide, nNodes, block, unitOf, leafUnit);
+        hipLaunchKernelGGL(packNodes, dim3(blocks(nNodes)), dim3(256), 0, nullptr, st->wide, nNodes, block, unitOf, static_cast<uint4*>(units));
         hipLaunchKernelGGL(leafRows, dim3(blocks(st->n)), dim3(256), 0, nullptr, st->sortedIds, (uint32_t)st->n, (uint32_t)st->nTris, dSlot,
-                           static_cast<const float4*>(dTriAccel), reinterpret_cast<const float4*>(st->dSpheres), static_cast<float4*>(rowsA),
-                           static_cast<float4*>(rowsBC));
+                           static_cast<const float4*>(dTriAccel), reinterpret_cast<const float4*>(st->dSpheres), leafUnit, static_cast<float4*>(units));
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
-        (void)hipFree(nodesOut); (void)hipFree(rowsA); (void)hipFree(rowsBC);
+        (void)hipFree(units);
         err = std::string("device builder: ") + hipGetErrorString(e);
         return e == hipErrorOutOfMemory ? YART_ERR_OUT_OF_MEMORY : YART_ERR_HIP;
     }
-    out.nodes = nodesOut; out.rowsA = rowsA; out.rowsBC = rowsBC;
+    out.units = units; out.numUnits = numUnits;
     out.numNodes = st->wideCount; out.numPrims = st->n; out.depth = st->wideDepth;
     out.msBuild = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - st->t0).count();
     out.msTopology = st->msTopology;
