@@ -386,7 +386,13 @@ hipError_t launchW(const WideParams& P, bool persistent, int numCUs, hipStream_t
         if (e != hipSuccess) return e;
         if (perCU < 1) perCU = 1;
         if (perCU > 8) perCU = 8;
-        if (P.maxBlocksPerCU && perCU > (int)P.maxBlocksPerCU) perCU = (int)P.maxBlocksPerCU;
+        // Waves resident per SIMD (= blocks per CU).  A wave's step takes the longer the more waves share its SIMD,
+        // and the launch ends with the longest rays of the last chunks, a drain at ever lower occupancy whose length
+        // is a fixed number of steps: the smaller the batch, the more of its time is that drain, and the fewer,
+        // faster waves pay (profiles/r02_exp_waves_per_simd.txt: 2^20 rays 4 waves -13 %, 2^22 rays 6 waves -8 %).
+        int want = P.n >= (1u << 23) ? 7 : P.n >= (1u << 22) ? 6 : P.n >= (1u << 21) ? 5 : P.n >= (1u << 20) ? 4 : P.n >= (1u << 19) ? 3 : 2;
+        if (P.maxBlocksPerCU) want = (int)P.maxBlocksPerCU;
+        if (perCU > want) perCU = want;
         uint32_t grid = (uint32_t)numCUs * (uint32_t)perCU;
         const uint32_t need = (P.n + P.chunk - 1) / P.chunk;
         const uint32_t needBlocks = (need + 3) / 4;
