@@ -87,7 +87,8 @@ struct YartAccel {
 
 namespace yart {
 
-constexpr size_t kCounterBlockBytes = 1024;      // 4 work-counter slots of 256 bytes
+constexpr uint32_t kDeferCap = 16384;             // rays the wide kernel can list for the fix-up launches of one call
+constexpr size_t kCounterBlockBytes = 1024 + size_t(kDeferCap) * 4;   // 4 work-counter slots of 256 bytes + that list
 
 // Scratch of one intersect call.  counters: kCounterBlockBytes of device memory.
 struct CallScratch {

@@ -211,6 +211,8 @@ int runIntersect(YartAccel* a, const Launch& L, const CallScratch* given)
         W.hits = P.hits; W.occluded = P.occluded; W.counts = P.counts;
         W.workCounter = slot0;
         W.deferFlag = W.workCounter + 1;
+        W.deferList = slot0 + 256;                  // behind the four counter slots (accel.h: kCounterBlockBytes)
+        W.deferCap = yart::kDeferCap;
         W.refillMin = a->wideRefillMin; W.nodeMin = a->wideNodeMin; W.chunk = a->wideChunk; W.maxBlocksPerCU = a->wideBlocksPerCU;
         {
             ScopedSpan span(a, 2, L.stream);
@@ -218,6 +220,8 @@ int runIntersect(YartAccel* a, const Launch& L, const CallScratch* given)
         }
         // rays the wide kernel does not take (!regularRay) are answered on the reference tree
         P.deferFlag = W.deferFlag;
+        P.deferList = W.deferList;
+        P.deferCap = W.deferCap;
         P.onlyDeferred = 1;
         fixupOnly = true;
     }

@@ -21,8 +21,12 @@ struct TraceParams {
     uint32_t chained;           // 1: triangle pass running after the sphere pass (hits/occluded/counts hold its results)
     uint32_t refillMin;         // persistent launch: refill a wave once this many lanes are idle
     uint32_t nodeMin;           // leave the descend loop when fewer lanes than this are at interior nodes
-    const uint32_t* deferFlag;  // fix-up launch after the wide kernel: *deferFlag != 0 iff it left rays behind
-    uint32_t onlyDeferred;      // 1: trace only the rays the wide kernel deferred (!regularRay)
+    const uint32_t* deferFlag;  // fix-up launch after the wide kernel: deferFlag[0] = rays it left behind, deferFlag[1] != 0: more
+                                // than its list holds
+    const uint32_t* deferList;  // their ray numbers, deferFlag[0] of them (at most deferCap)
+    uint32_t deferCap;
+    uint32_t onlyDeferred;      // 1: trace only the rays the wide kernel deferred (!regularRay): the listed ones, or -- when the
+                                // list overflowed -- every ray of the batch that is not regularRay()
 };
 
 // The wide-tree kernel (traverse_wide.hip) handles "regular" rays: finite origin, finite non-zero
@@ -51,7 +55,10 @@ struct WideParams {
     uint8_t* occluded;
     uint32_t* counts;
     uint32_t* workCounter;      // 256-byte slot zeroed by the launcher: counters at words 0, 8, .. 56
-    uint32_t* deferFlag;        // word 1 of the same slot: set when a ray was left for the fix-up launch
+    uint32_t* deferFlag;        // words 1, 2 of the same slot: rays left for the fix-up launches (counted, and listed in deferList
+                                // while it has room) / set when the list overflowed
+    uint32_t* deferList;
+    uint32_t deferCap;
     uint32_t refillMin;
     uint32_t nodeMin;
     uint32_t maxBlocksPerCU;    // 0 = as many as fit (8)

@@ -143,7 +143,16 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceParams P)
     uint32_t rangesDone = 0;
     const int refillMin = (int)P.refillMin;
     const int nodeMin = (int)P.nodeMin;
-    if (P.onlyDeferred && *P.deferFlag == 0) return;     // uniform: nothing was deferred
+    // Fix-up launch after the wide kernel: the rays it listed (or, when its list overflowed, every ray of the batch
+    // that is not regularRay()); nothing to do when it deferred none.  Wave-uniform.
+    uint32_t nRays = P.n;
+    const uint32_t* perm = P.perm;
+    bool listed = false;
+    if (P.onlyDeferred) {
+        const uint32_t c = P.deferFlag[0];
+        if (c == 0) return;
+        if (P.deferFlag[1] == 0 && c <= P.deferCap) { nRays = c; perm = P.deferList; listed = true; }
+    }
 
     auto push = [&](uint32_t v) {
         if (sp < kLdsStack) ldsStack[sp * kBlock + tid] = v;
@@ -157,13 +166,13 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceParams P)
     };
 
     auto startRay = [&](uint32_t slot) {
-        rayId = P.perm ? P.perm[slot] : slot;
+        rayId = perm ? perm[slot] : slot;
         const float4 a = P.rays[(size_t)rayId * 2 + 0];
         const float4 b = P.rays[(size_t)rayId * 2 + 1];
         r.ox = a.x; r.oy = a.y; r.oz = a.z; r.tmin = a.w;
         r.dx = b.x; r.dy = b.y; r.dz = b.z; r.tmax = b.w;
         r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
-        if (P.onlyDeferred && regularRay(r.ox, r.oy, r.oz, r.tmin, r.dx, r.dy, r.dz, r.tmax)) {
+        if (P.onlyDeferred && !listed && regularRay(r.ox, r.oy, r.oz, r.tmin, r.dx, r.dy, r.dz, r.tmax)) {
             live = false; cur = kIdle; sp = 0;           // the wide kernel has answered this ray
             return;
         }
@@ -199,7 +208,7 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceParams P)
                 // then helps with the other ranges.
                 while (chunkNext == chunkEnd && !exhausted) {
                     const uint32_t range = (homeXcd + rangesDone) & 7u;
-                    const uint32_t rBegin = rangeBegin(P.n, range), rEnd = rangeBegin(P.n, range + 1);
+                    const uint32_t rBegin = rangeBegin(nRays, range), rEnd = rangeBegin(nRays, range + 1);
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(P.workCounter + range * 8, kChunk);
                     base = __builtin_amdgcn_readfirstlane(base) + rBegin;
@@ -220,7 +229,7 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceParams P)
         } else {
             if (firstPass) {
                 const uint32_t slot = blockIdx.x * kBlock + tid;
-                if (slot < P.n) startRay(slot);
+                if (slot < nRays) startRay(slot);
                 firstPass = false;
             }
             if (__ballot(cur != kIdle) == 0) break;

@@ -174,7 +174,12 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
         const float4 a = P.rays[(size_t)rayId * 2 + 0];
         const float4 b = P.rays[(size_t)rayId * 2 + 1];
         if (!regularRay(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w)) {
-            *P.deferFlag = 1u;                     // answered by the fix-up launch on the reference tree
+            // answered by the fix-up launches on the reference tree, which take the listed rays only; a batch with
+            // more such rays than the list holds is scanned whole (no atomic once the list is full)
+            uint32_t c = __hip_atomic_load(P.deferFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c < P.deferCap) c = atomicAdd(P.deferFlag, 1u);
+            if (c < P.deferCap) P.deferList[c] = rayId;
+            else P.deferFlag[1] = 1u;
             return;
         }
         r.ox = a.x; r.oy = a.y; r.oz = a.z;
@@ -367,9 +372,9 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
 #ifdef YART_STEP_STATS
     // experiment builds only (make EXTRA=-DYART_STEP_STATS): how full the waves are in the two phases
     if (lane == 0) {
-        atomicAdd(P.workCounter + 2, stNodeSteps); atomicAdd(P.workCounter + 3, stNodeLanes >> 6);
-        atomicAdd(P.workCounter + 4, stLeafSteps); atomicAdd(P.workCounter + 5, stLeafLanes >> 6);
-        atomicAdd(P.workCounter + 6, stIters); atomicAdd(P.workCounter + 7, stLive >> 6);
+        atomicAdd(P.workCounter + 9, stNodeSteps); atomicAdd(P.workCounter + 10, stNodeLanes >> 6);
+        atomicAdd(P.workCounter + 11, stLeafSteps); atomicAdd(P.workCounter + 12, stLeafLanes >> 6);
+        atomicAdd(P.workCounter + 13, stIters); atomicAdd(P.workCounter + 14, stLive >> 6);
     }
 #endif
 }
@@ -400,7 +405,7 @@ hipError_t launchW(const WideParams& P, bool persistent, int numCUs, hipStream_t
         hipLaunchKernelGGL((traceWide<ANY, COUNT, true>), dim3(grid), dim3(kBlock), 0, stream, P);
 #ifdef YART_STEP_STATS
         uint32_t st[8];
-        if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(st, P.workCounter, sizeof st, hipMemcpyDeviceToHost) == hipSuccess && P.n > 1000000)
+        if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(st + 2, P.workCounter + 9, 6 * 4, hipMemcpyDeviceToHost) == hipSuccess && P.n > 1000000)
             fprintf(stderr, "step stats (%u rays, any=%d): node steps %u, mean lanes %.1f; leaf steps %u, mean lanes %.1f; outer iterations %u, mean live lanes %.1f\n",
                     P.n, (int)ANY, st[2], 64.0 * st[3] / (st[2] ? st[2] : 1), st[4], 64.0 * st[5] / (st[4] ? st[4] : 1), st[6], 64.0 * st[7] / (st[6] ? st[6] : 1));
 #endif
