@@ -302,10 +302,14 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
     std::string err;
     const char* noWide = std::getenv("YART_NO_WIDE");
     const bool wantWide = !(noWide && noWide[0] == '1');
-    // YART_BUILD_DEVICE=1: the 4-wide tree is built on the GPU (wide_build_dev.hip).  Its first phase needs only
-    // the scene and runs in a thread of its own while this one builds the reference's tree.
+    // The 4-wide tree is built on the GPU (wide_build_dev.hip) for scenes of 2^18 primitives and more -- the host builder
+    // (binned SAH on a thread pool) needs 3.8 s for the 11 M primitives of BASELINE configs[3], the device 0.1 s for a
+    // tree the traversal kernel walks 1-2 % slower -- and on the host below that, where it takes no time;
+    // YART_BUILD_DEVICE=1 / 0 decide for every size.  The builder's first phase needs only the scene and runs in a
+    // thread of its own.
     const char* devBuild = std::getenv("YART_BUILD_DEVICE");
-    const bool wantDeviceBuild = wantWide && devBuild && devBuild[0] == '1' && n_tris + n_spheres >= 2;
+    const bool deviceByDefault = n_tris + n_spheres >= (size_t(1) << 18);
+    const bool wantDeviceBuild = wantWide && (devBuild ? devBuild[0] == '1' : deviceByDefault) && n_tris + n_spheres >= 2;
     const auto tBuild0 = std::chrono::steady_clock::now();
     yart::DeviceWideBuilder devBuilder;
     std::thread devThread;

@@ -158,7 +158,8 @@ __device__ inline int prefix(const uint64_t* codes, int n, int i, int j)
 
 // Internal node i of n - 1; leaf j is node (n - 1) + j.  left/right: child node numbers.
 __global__ void __launch_bounds__(256) hierarchy(const uint64_t* __restrict__ codes, int n, uint32_t* __restrict__ left,
-                                                 uint32_t* __restrict__ right, uint32_t* __restrict__ parent)
+                                                 uint32_t* __restrict__ right, uint32_t* __restrict__ parent,
+                                                 uint32_t* __restrict__ rangeLo, uint32_t* __restrict__ rangeHi)
 {
     const int i = (int)(blockIdx.x * 256u + threadIdx.x);
     if (i >= n - 1) return;
@@ -183,9 +184,150 @@ __global__ void __launch_bounds__(256) hierarchy(const uint64_t* __restrict__ co
     const uint32_t rc = (last == gamma + 1) ? (uint32_t)(n - 1 + gamma + 1) : (uint32_t)(gamma + 1);
     left[i] = lc;
     right[i] = rc;
+    rangeLo[i] = (uint32_t)first;
+    rangeHi[i] = (uint32_t)last;
     parent[lc] = (uint32_t)i;
     parent[rc] = (uint32_t)i;
     if (i == 0) parent[0] = kNoParent;
+}
+
+// ---- SAH below the Morton order.  Where a linear BVH loses against binned SAH is in its subtrees of a few hundred
+// primitives (profiles/r02_exp_hybrid_tree_quality.txt: Morton splits down to 256 primitives and SAH below give the
+// SAH tree's node visits within 1 %, Morton splits all the way 6 % more).  So every maximal subtree of at most T
+// primitives is split again, top-down with binned SAH (16 bins, three axes, as wide_build.cpp), by ONE thread: the
+// subtrees are independent, there are tens of thousands of them, and each is a few thousand operations on 12 KB.
+// The subtree over sorted positions [f, l] keeps its root; its other l - f - 1 internal nodes are exactly the
+// numbers f + 1 .. l - 1 (every internal node of the radix tree is numbered by an end of its range, a left child
+// by the last position, a right child by the first), which the new topology reuses; the primitives are permuted
+// inside [f, l] only.
+__global__ void __launch_bounds__(256) treeletRoots(const uint32_t* __restrict__ rangeLo, const uint32_t* __restrict__ rangeHi,
+                                                    const uint32_t* __restrict__ parent, uint32_t nInternal, uint32_t maxSize,
+                                                    uint32_t* __restrict__ roots, uint32_t* __restrict__ count)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    bool root = false;
+    if (i < nInternal) {
+        const uint32_t size = rangeHi[i] - rangeLo[i] + 1u;
+        if (size >= 3u && size <= maxSize) {
+            const uint32_t p = parent[i];
+            root = p == kNoParent || rangeHi[p] - rangeLo[p] + 1u > maxSize;
+        }
+    }
+    const uint64_t m = __ballot(root);
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == 0 && m) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = __shfl(base, 0);
+    if (root) roots[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+}
+
+struct SahBins { float lo[16][3], hi[16][3]; uint32_t cnt[16]; };
+
+__device__ inline float boxHalfArea(const float* lo, const float* hi)
+{
+    const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    if (!(dx >= 0.0f && dy >= 0.0f && dz >= 0.0f)) return 0.0f;
+    return dx * dy + dy * dz + dz * dx;
+}
+
+__global__ void __launch_bounds__(64) treeletSah(const uint32_t* __restrict__ roots, const uint32_t* __restrict__ nRoots,
+                                                 const uint32_t* __restrict__ rangeLo, const uint32_t* __restrict__ rangeHi, uint32_t nLeaves,
+                                                 uint32_t* __restrict__ sortedIds, const float4* __restrict__ primLo, const float4* __restrict__ primHi,
+                                                 uint32_t* __restrict__ left, uint32_t* __restrict__ right, uint32_t* __restrict__ parent)
+{
+    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+    if (t >= *nRoots) return;
+    const uint32_t rootNode = roots[t];
+    const uint32_t f = rangeLo[rootNode], l = rangeHi[rootNode];
+    uint32_t nextId = f + 1u;                       // internal nodes f + 1 .. l - 1 are this subtree's to reuse
+    constexpr int kBins = 16;
+    struct Todo { uint32_t node, b, e; };
+    Todo stack[12];                                 // the larger part of every split waits here: at most log2(T) + 1 entries
+    int sp = 0;
+    Todo cur{ rootNode, f, l + 1u };
+    for (;;) {
+        const uint32_t count = cur.e - cur.b;       // >= 2
+        float cLo[3] = { __builtin_inff(), __builtin_inff(), __builtin_inff() }, cHi[3] = { -__builtin_inff(), -__builtin_inff(), -__builtin_inff() };
+        for (uint32_t i = cur.b; i < cur.e; ++i) {
+            const uint32_t id = sortedIds[i];
+            const float4 pl = primLo[id], ph = primHi[id];
+            const float c[3] = { 0.5f * pl.x + 0.5f * ph.x, 0.5f * pl.y + 0.5f * ph.y, 0.5f * pl.z + 0.5f * ph.z };
+            for (int a = 0; a < 3; ++a) { cLo[a] = fminf(cLo[a], c[a]); cHi[a] = fmaxf(cHi[a], c[a]); }
+        }
+        int bestAxis = -1, bestSplit = 0;
+        float bestCost = __builtin_inff(), bestLo = 0.0f, bestScale = 0.0f;
+        for (int a = 0; a < 3; ++a) {
+            const float ext = cHi[a] - cLo[a];
+            if (!(ext > 0.0f) || !(ext < __builtin_inff())) continue;
+            SahBins bins;
+            for (int k = 0; k < kBins; ++k) {
+                bins.cnt[k] = 0;
+                for (int d = 0; d < 3; ++d) { bins.lo[k][d] = __builtin_inff(); bins.hi[k][d] = -__builtin_inff(); }
+            }
+            const float scale = (float)kBins / ext;
+            for (uint32_t i = cur.b; i < cur.e; ++i) {
+                const uint32_t id = sortedIds[i];
+                const float4 pl = primLo[id], ph = primHi[id];
+                const float pc = a == 0 ? 0.5f * pl.x + 0.5f * ph.x : (a == 1 ? 0.5f * pl.y + 0.5f * ph.y : 0.5f * pl.z + 0.5f * ph.z);
+                int k = (int)((pc - cLo[a]) * scale);
+                k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                bins.lo[k][0] = fminf(bins.lo[k][0], pl.x); bins.lo[k][1] = fminf(bins.lo[k][1], pl.y); bins.lo[k][2] = fminf(bins.lo[k][2], pl.z);
+                bins.hi[k][0] = fmaxf(bins.hi[k][0], ph.x); bins.hi[k][1] = fmaxf(bins.hi[k][1], ph.y); bins.hi[k][2] = fmaxf(bins.hi[k][2], ph.z);
+                ++bins.cnt[k];
+            }
+            float rightArea[kBins];
+            uint32_t rightCnt[kBins];
+            float accLo[3] = { __builtin_inff(), __builtin_inff(), __builtin_inff() }, accHi[3] = { -__builtin_inff(), -__builtin_inff(), -__builtin_inff() };
+            uint32_t c = 0;
+            for (int k = kBins - 1; k > 0; --k) {
+                for (int d = 0; d < 3; ++d) { accLo[d] = fminf(accLo[d], bins.lo[k][d]); accHi[d] = fmaxf(accHi[d], bins.hi[k][d]); }
+                c += bins.cnt[k];
+                rightArea[k] = boxHalfArea(accLo, accHi);
+                rightCnt[k] = c;
+            }
+            for (int d = 0; d < 3; ++d) { accLo[d] = __builtin_inff(); accHi[d] = -__builtin_inff(); }
+            c = 0;
+            for (int k = 1; k < kBins; ++k) {              // split k: bins [0, k) left, [k, kBins) right
+                for (int d = 0; d < 3; ++d) { accLo[d] = fminf(accLo[d], bins.lo[k - 1][d]); accHi[d] = fmaxf(accHi[d], bins.hi[k - 1][d]); }
+                c += bins.cnt[k - 1];
+                if (c == 0 || rightCnt[k] == 0) continue;
+                const float cost = boxHalfArea(accLo, accHi) * (float)c + rightArea[k] * (float)rightCnt[k];
+                if (cost < bestCost) { bestCost = cost; bestAxis = a; bestSplit = k; bestLo = cLo[a]; bestScale = scale; }
+            }
+        }
+        uint32_t mid = cur.b + count / 2u;                  // all centres coincide: halve the range as it stands
+        if (bestAxis >= 0) {
+            uint32_t i = cur.b, j = cur.e;                  // in-place partition: bin < bestSplit to the front
+            while (i < j) {
+                const uint32_t id = sortedIds[i];
+                const float4 pl = primLo[id], ph = primHi[id];
+                const float pc = bestAxis == 0 ? 0.5f * pl.x + 0.5f * ph.x : (bestAxis == 1 ? 0.5f * pl.y + 0.5f * ph.y : 0.5f * pl.z + 0.5f * ph.z);
+                int k = (int)((pc - bestLo) * bestScale);
+                k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                if (k < bestSplit) ++i;
+                else { --j; sortedIds[i] = sortedIds[j]; sortedIds[j] = id; }
+            }
+            if (i > cur.b && i < cur.e) mid = i;
+        }
+        const uint32_t nl = mid - cur.b, nr = cur.e - mid;
+        const uint32_t childL = nl == 1u ? nLeaves - 1u + cur.b : nextId++;
+        const uint32_t childR = nr == 1u ? nLeaves - 1u + mid : nextId++;
+        left[cur.node] = childL;
+        right[cur.node] = childR;
+        parent[childL] = cur.node;
+        parent[childR] = cur.node;
+        const Todo tl{ childL, cur.b, mid }, tr{ childR, mid, cur.e };
+        // the smaller part next, the larger waits: the stack stays logarithmic
+        const bool leftFirst = nl <= nr;
+        const Todo& first = leftFirst ? tl : tr;
+        const Todo& second = leftFirst ? tr : tl;
+        const uint32_t nFirst = leftFirst ? nl : nr, nSecond = leftFirst ? nr : nl;
+        if (nSecond >= 2u && nFirst >= 2u) { stack[sp++] = second; cur = first; continue; }
+        if (nFirst >= 2u) { cur = first; continue; }
+        if (nSecond >= 2u) { cur = second; continue; }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
 }
 
 // depth of the children of every internal node at depth `level`; *any = 1 if there was such a node
@@ -603,14 +745,32 @@ int DeviceWideBuilder::topology(const float* verts, size_t nVerts, const int32_t
 
     // topology
     const size_t nInternal = n - 1, nNodes = 2 * n - 1;
-    uint32_t *left, *right, *parent, *depth, *dAny;
+    uint32_t *left, *right, *parent, *depth, *dAny, *rangeLo, *rangeHi, *roots;
     YART_HIP(S.alloc(&left, nInternal));
     YART_HIP(S.alloc(&right, nInternal));
+    YART_HIP(S.alloc(&rangeLo, nInternal));
+    YART_HIP(S.alloc(&rangeHi, nInternal));
+    YART_HIP(S.alloc(&roots, nInternal));
     YART_HIP(S.alloc(&parent, nNodes));
     YART_HIP(S.alloc(&depth, nNodes));
     YART_HIP(S.alloc(&dAny, 64));
-    hipLaunchKernelGGL(hierarchy, dim3(blocks(nInternal)), dim3(256), 0, nullptr, codes, (int)n, left, right, parent);
+    hipLaunchKernelGGL(hierarchy, dim3(blocks(nInternal)), dim3(256), 0, nullptr, codes, (int)n, left, right, parent, rangeLo, rangeHi);
     YART_HIP(hipGetLastError());
+    YART_HIP(hipMemsetAsync(dAny, 0, 256, nullptr));
+    {
+        // binned SAH inside the subtrees of at most `treelet` primitives (YART_DEVICE_TREELET, 0 = keep the Morton splits)
+        uint32_t treelet = 256;
+        if (const char* v = std::getenv("YART_DEVICE_TREELET")) treelet = static_cast<uint32_t>(std::atoi(v));
+        if (treelet > 2048) treelet = 2048;             // treeletSah's stack: log2 of it + 1 entries
+        if (treelet >= 3) {
+            hipLaunchKernelGGL(treeletRoots, dim3(blocks(nInternal)), dim3(256), 0, nullptr, rangeLo, rangeHi, parent, (uint32_t)nInternal, treelet, roots, dAny + 32);
+            // one thread per root: the count stays on the device, the grid covers the most there can be
+            const size_t maxRoots = nInternal / 2 + 1;
+            hipLaunchKernelGGL(treeletSah, dim3(static_cast<uint32_t>((maxRoots + 63) / 64)), dim3(64), 0, nullptr, roots, dAny + 32, rangeLo, rangeHi, (uint32_t)n,
+                               const_cast<uint32_t*>(sortedIds), primLo, primHi, left, right, parent);
+            YART_HIP(hipGetLastError());
+        }
+    }
     YART_HIP(hipMemsetAsync(depth, 0xFF, nNodes * 4, nullptr));
     YART_HIP(hipMemsetAsync(depth, 0, 4, nullptr));        // the root, internal node 0
     YART_HIP(hipMemsetAsync(dAny, 0, 256, nullptr));
