@@ -36,13 +36,14 @@ def log(*a):
 def algorithmic_bytes(counts, wide, chained):
     """ray in (32 B) + hit out (16 B) + the records the engine's own traversal
     fetched, per ray and per kernel, from the counting kernel (include/yart_amd.h):
-      default 4-wide tree : 16 B per child record + 16 B per triangle plane row + 32 B per
-                            second-stage row + 16 B per sphere record
+      default 4-wide tree : 48 B per node visit = 12 B per child record (four per visit; the packed node of
+                            yart_amd/csrc/wide_build.h) + 16 B per triangle plane row + 32 B per second-stage
+                            row + 16 B per sphere record
       reference tree      : 32 B per node record + 48 B per triangle record (+ sphere tree)"""
     c = counts.sum(0).astype(np.float64)
     n = float(len(counts))
     if wide:
-        return n * (32 + 16) + 16.0 * c[0] + 16.0 * c[1] + 32.0 * c[2] + 16.0 * c[3], 0.0
+        return n * (32 + 16) + 12.0 * c[0] + 16.0 * c[1] + 32.0 * c[2] + 16.0 * c[3], 0.0
     tri = n * (32 + 16 + (16 if chained else 0)) + 32.0 * c[0] + 48.0 * c[1]
     sph = (n * (32 + 16) + 32.0 * c[2] + 16.0 * c[3]) if chained else 0.0
     return tri, sph
@@ -211,7 +212,7 @@ def main():
         "algorithmic_GBps": round(algorithmic, 1),
         "algorithmic_bytes_per_launch": int(bytes_tri),
         "algorithmic_bytes_per_ray": round(bytes_tri / args.rays, 1),
-        "per_ray_fetches": ({"child_records_16B": round(float(mean_counts[0]), 2),
+        "per_ray_fetches": ({"child_records_12B": round(float(mean_counts[0]), 2),
                              "triangle_plane_rows_16B": round(float(mean_counts[1]), 2),
                              "second_stage_rows_32B": round(float(mean_counts[2]), 2),
                              "sphere_records_16B": round(float(mean_counts[3]), 2)} if wide else
@@ -236,8 +237,9 @@ def main():
     out["roofline"]["stream_copy_GBps"] = round(copy_gbs, 1)
     out["roofline"]["note"] = ("achieved = HBM-side bytes per launch (PMC, separate passes of this command; see traffic_source) / "
                                "this run's kernel time; frac = achieved / 8 TB/s.  algorithmic_GBps counts every fetch the traversal "
-                               "issues, cached or not: 70% of them are served by L2, so it is not a roofline fraction.  The kernel is "
-                               "bound by instruction issue and per-lane L1 requests, not by bytes (DESIGN.md 3.1)"
+                               "issues, cached or not: most of them are served by L1 / L2, so it is not a roofline fraction.  The kernel is "
+                               "bound by vector-instruction issue (a wave's step costs the same however many lanes take part), "
+                               "not by bytes (DESIGN.md 3.1)"
                                if achieved is not None else
                                "no PMC traffic figure for this configuration in profiles/traffic.json: HBM-side rate not available; "
                                "algorithmic_GBps counts every fetch, cached or not")

@@ -201,11 +201,12 @@ size_t yart_accel_num_wide_nodes(const YartAccel* accel);
 size_t yart_accel_num_wide_prims(const YartAccel* accel);
 int yart_accel_wide_depth(const YartAccel* accel);
 int yart_accel_get_wide(const YartAccel* accel, void* nodes_out, void* rows_a_out, void* rows_bc_out);
-/* 1 if the 4-wide tree of this accel was built on the GPU (environment YART_BUILD_DEVICE=1 at create:
- * Morton-ordered linear BVH, collapse plan, quantised nodes and leaf rows by kernels, while the host
- * builds the reference's tree; no counterpart in the reference, whose build is src/bvhaccel.cpp:100-151),
- * 0 if the host builder made it (the default: binned SAH, better trees, seconds for 10^7 primitives).
- * ms_out (optional): wall milliseconds of the device build. */
+/* 1 if the 4-wide tree of this accel was built on the GPU (Morton-ordered linear BVH whose subtrees of <= 256
+ * primitives are split again with binned SAH, collapse plan, quantised nodes and leaf rows by kernels; no
+ * counterpart in the reference, whose build is src/bvhaccel.cpp:100-151), 0 if the host builder made it (binned
+ * SAH on a thread pool: seconds for 10^7 primitives, a tree the kernel walks 1-2 % faster).  The GPU builds scenes
+ * of 2^18 primitives and more unless the environment says otherwise at create (YART_BUILD_DEVICE=1 / 0: always /
+ * never).  ms_out (optional): wall milliseconds of the device build. */
 int yart_accel_wide_built_on_device(const YartAccel* accel, double* ms_out);
 /* 1 if the reference's own arrays of this accel -- the flattened nodes in the reference's order, the TriAccel
  * records in its leaf order: what BvhAccel's constructor builds on one host thread, src/bvhaccel.cpp:100-151,
