@@ -88,3 +88,27 @@ def test_tiny_scenes_fall_back_to_the_host_builder():
     got = api.hits_to_numpy(acc.intersect_closest(dev(scenes.random_rays(1000, seed=1))))
     assert got["prim"].max() <= 0
     acc.close()
+
+
+def test_host_builders_still_serve_large_scenes_on_request(monkeypatch):
+    """From 2^18 primitives the device builds by default; YART_BUILD_DEVICE=0 must keep giving the host-built trees
+    (binned SAH / std::partition recursion), with the same answers."""
+    from oracle import oracle as orc
+    v, t, s = scenes.random_soup(300000, 3000, s=0.01, seed=17)
+    rays = scenes.random_rays(1 << 17, seed=5)
+    out = {}
+    for mode in ("default", "0"):
+        if mode == "0":
+            monkeypatch.setenv("YART_BUILD_DEVICE", "0")
+        else:
+            monkeypatch.delenv("YART_BUILD_DEVICE", raising=False)
+        acc = api.Accel(v, t, s)
+        assert acc.wide_built_on_device[0] == (mode == "default")
+        assert acc.ref_built_on_device[0] == (mode == "default")
+        out[mode] = (api.hits_to_numpy(acc.intersect_closest(dev(rays))), acc.nodes().tobytes(), acc.triaccel().tobytes())
+        acc.close()
+    assert out["default"][1] == out["0"][1] and out["default"][2] == out["0"][2]      # the reference's arrays: identical
+    want = orc.Oracle(v, t, s).intersect(rays, mode=0, nthreads=16)
+    for mode in out:
+        assert_within_bar(out[mode][0], want["prim"], want["t"])
+    assert np.array_equal(out["default"][0]["prim"], out["0"][0]["prim"]) and np.array_equal(bits(out["default"][0]["t"]), bits(out["0"][0]["t"]))
