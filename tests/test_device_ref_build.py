@@ -175,3 +175,30 @@ def test_surface_records_need_the_leaf_order_from_the_device(monkeypatch):
     assert out[0][0].tobytes() == out[1][0].tobytes()
     assert out[0][1].tobytes() == out[1][1].tobytes()
     assert out[0][2:] == out[1][2:]
+
+
+def test_sphere_tree_of_the_reference_tree_path_built_on_the_device(monkeypatch):
+    """From 1024 spheres the sphere tree the reference-tree kernels walk comes from the same device builder; the
+    reference rule over it must be bit-exact against the oracle (which loops over the spheres like the reference) and
+    identical to what the host-built accel returns, ties between duplicate spheres included."""
+    from oracle import oracle as orc
+    v, t, s = scenes.random_soup(6000, 5000, s=0.04, seed=31)
+    s = np.concatenate([s, s[:200], np.array([[0.5, 0.5, 0.5, 0.0]] * 3, np.float32)])      # duplicates, zero radius
+    rays = scenes.random_rays(1 << 16, seed=6)
+    shadow = rays.copy()
+    shadow[:, 7] = 0.4
+    out = []
+    for device in ("1", "0"):
+        monkeypatch.setenv("YART_BUILD_DEVICE", device)
+        acc = api.Accel(v, t, s)
+        out.append((acc.intersect_closest(dev(rays), api.YART_REFERENCE_RULE).cpu().numpy().copy(),
+                    acc.intersect_any(dev(shadow), api.YART_REFERENCE_RULE).cpu().numpy().copy(),
+                    acc.intersect_closest(dev(rays), api.YART_REFERENCE_TREE).cpu().numpy().copy()))
+        acc.close()
+    for k in range(3):
+        assert out[0][k].tobytes() == out[1][k].tobytes()
+    o = orc.Oracle(v, t, s)
+    want = o.intersect(rays, mode=0, nthreads=16)
+    got = api.hits_to_numpy(torch.from_numpy(out[0][0]))
+    assert_exact(got, want["prim"], want["t"], want["u"], want["v"])
+    assert np.array_equal(out[0][1], o.intersect_shadow(shadow, mode=0, nthreads=16))

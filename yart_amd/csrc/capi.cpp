@@ -333,17 +333,27 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
     }
     yart::SphereBvh sph;
     yart::DeviceRefTree devRef;
-    bool refOnDevice = false;
+    yart::DeviceSphereTree devSph;
+    bool refOnDevice = false, sphOnDevice = false;
     int st = YART_OK;
     if (wantDeviceRef) {
-        st = yart::buildSphereBvh(spheres, n_spheres, sph, err);       // on the host while the device sorts
+        // the sphere tree of the reference-tree path: on the host while the device sorts, or -- from 1024 spheres --
+        // by the same device builder afterwards
+        const bool wantDeviceSph = n_spheres >= 1024;
+        if (!wantDeviceSph) st = yart::buildSphereBvh(spheres, n_spheres, sph, err);
         devThread.join();
         if (st == YART_OK && devStatus == YART_OK) {
             bool useHost = false;
             st = yart::buildReferenceTreeDevice(devBuilder.deviceVerts(), verts, n_verts, devBuilder.deviceTris(), tris, n_tris, devRef, &useHost, err);
             refOnDevice = st == YART_OK && !useHost;
+            if (st == YART_OK && wantDeviceSph) {
+                useHost = false;
+                st = yart::buildSphereTreeDevice(devBuilder.deviceSpheres(), n_spheres, devSph, &useHost, err);
+                sphOnDevice = st == YART_OK && !useHost;
+            }
         }
         if (st == YART_OK && !refOnDevice) st = yart::buildTriangleBvh(verts, n_verts, tris, n_tris, a->tri, err);
+        if (st == YART_OK && wantDeviceSph && !sphOnDevice) st = yart::buildSphereBvh(spheres, n_spheres, sph, err);
     } else {
         st = yart::buildTriangleBvh(verts, n_verts, tris, n_tris, a->tri, err);
         if (st == YART_OK) st = yart::buildSphereBvh(spheres, n_spheres, sph, err);
@@ -357,14 +367,14 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
                                     // cheaper rejection than its plane row, and rows of different leaves are not tested
         st = yart::buildWideBvh(verts, n_verts, tris, n_tris, a->tri, spheres, n_spheres, maxLeaf, wide, err);
     }
-    if (st != YART_OK) { devRef.release(); delete a; return fail(st, err); }
+    if (st != YART_OK) { devRef.release(); devSph.release(); delete a; return fail(st, err); }
     a->numTriPairs = refOnDevice ? devRef.numPairs : a->tri.pairs.size();
     a->numTriangles = n_tris;
     a->numNodes = refOnDevice ? devRef.numNodes : a->tri.nodes.size();
     if (refOnDevice) a->tri.depth = devRef.depth;
-    a->numSphPairs = sph.pairs.size();
+    a->numSphPairs = sphOnDevice ? devSph.numPairs : sph.pairs.size();
     a->numSpheres = n_spheres;
-    a->sphDepth = sph.depth;
+    a->sphDepth = sphOnDevice ? devSph.depth : sph.depth;
 
     const float inf = std::numeric_limits<float>::infinity();
     for (int c = 0; c < 3; ++c) { a->sceneLo[c] = inf; a->sceneHi[c] = -inf; }
@@ -380,10 +390,15 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
         std::memcpy(root.hi, devRef.rootHi, 12);
         growBy(root);
     } else if (n_tris) growBy(a->tri.pairs[0].child[0]);
-    if (n_spheres) growBy(sph.pairs[0].child[0]);
+    if (sphOnDevice) {
+        yart::DevNodeRec root;
+        std::memcpy(root.lo, devSph.rootLo, 12);
+        std::memcpy(root.hi, devSph.rootHi, 12);
+        growBy(root);
+    } else if (n_spheres) growBy(sph.pairs[0].child[0]);
 
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { devRef.release(); delete a; return fail(YART_ERR_NO_DEVICE, "hipGetDeviceProperties failed"); }
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { devRef.release(); devSph.release(); delete a; return fail(YART_ERR_NO_DEVICE, "hipGetDeviceProperties failed"); }
     a->numCUs = prop.multiProcessorCount;
 
     if (refOnDevice) {
@@ -404,9 +419,18 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
         st = upload(&a->dTriPairs, a->tri.pairs.data(), a->tri.pairs.size() * sizeof(yart::DevNodePair), a->deviceBytes);
         if (st == YART_OK) st = upload(&a->dTriAccel, a->tri.triaccel.data(), a->tri.triaccel.size() * sizeof(YartTriAccel), a->deviceBytes);
     }
-    if (st == YART_OK) st = upload(&a->dSphPairs, sph.pairs.data(), sph.pairs.size() * sizeof(yart::DevNodePair), a->deviceBytes);
-    if (st == YART_OK) st = upload(&a->dSphRecs, sph.records.data(), sph.records.size() * sizeof(float), a->deviceBytes);
-    if (st == YART_OK) st = upload(&a->dSphIndex, sph.index.data(), sph.index.size() * sizeof(uint32_t), a->deviceBytes);
+    if (sphOnDevice) {
+        a->dSphPairs = devSph.pairs;
+        a->dSphRecs = devSph.records;
+        a->dSphIndex = devSph.index;
+        a->deviceBytes += devSph.numPairs * sizeof(yart::DevNodePair) + n_spheres * 20;
+        if (std::getenv("YART_BUILD_TIMING"))
+            fprintf(stderr, "device sphere-tree build: %.1f ms (%zu pairs, depth %d)\n", devSph.ms, devSph.numPairs, devSph.depth);
+    } else {
+        if (st == YART_OK) st = upload(&a->dSphPairs, sph.pairs.data(), sph.pairs.size() * sizeof(yart::DevNodePair), a->deviceBytes);
+        if (st == YART_OK) st = upload(&a->dSphRecs, sph.records.data(), sph.records.size() * sizeof(float), a->deviceBytes);
+        if (st == YART_OK) st = upload(&a->dSphIndex, sph.index.data(), sph.index.size() * sizeof(uint32_t), a->deviceBytes);
+    }
     if (st == YART_OK && useDeviceBuild) {
         // second phase of the device build: leaf rows from the reference's TriAccel records and leaf order
         yart::DeviceWide dw;

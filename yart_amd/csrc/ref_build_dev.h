@@ -31,4 +31,19 @@ struct DeviceRefTree {
 int buildReferenceTreeDevice(const float* dVerts, const float* verts, size_t nVerts, const int32_t* dTris, const int32_t* tris,
                              size_t nTris, DeviceRefTree& out, bool* useHost, std::string& err);
 
+// The engine's sphere tree of the reference-tree path (bvh_build.h: SphereBvh) from the same level-synchronous build:
+// leaves of at most 4 spheres, numbered left to right; identical to the host builder's arrays.
+struct DeviceSphereTree {
+    void* pairs = nullptr;          // DevNodePair[numPairs]
+    void* records = nullptr;        // 4 floats per sphere, leaf-slot order
+    void* index = nullptr;          // uint32: leaf slot -> sphere number
+    size_t numPairs = 0, numSpheres = 0;
+    int depth = 0;
+    float rootLo[3] = { 0, 0, 0 }, rootHi[3] = { 0, 0, 0 };
+    double ms = 0.0;
+    void release();
+};
+// dSpheres: 4 floats per sphere on the device.  *useHost as above (NaN, too many one-sided splits).
+int buildSphereTreeDevice(const float* dSpheres, size_t nSpheres, DeviceSphereTree& out, bool* useHost, std::string& err);
+
 } // namespace yart

@@ -43,6 +43,7 @@ namespace {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kLeafBelow = 8;              // src/bvhaccel.cpp:57 -- leaf iff count < 8
+constexpr uint32_t kSphereLeafBelow = 5;        // the engine's sphere tree: leaves of at most 4 (bvh_build.cpp buildSphereBvh)
 constexpr uint32_t kOneSided = 0x80000000u;     // flag in nSplit: the range was split at its median on the host
 constexpr uint32_t kFixCap = 1u << 16;          // most ranges / triangles fixed up on the host before giving up
 
@@ -182,12 +183,13 @@ __global__ void __launch_bounds__(1024) segBounds(const float4* __restrict__ rec
 
 // Leaf or split, widest axis (include/bbox.h:52-62) and midpoint (src/bvhaccel.cpp:125-127) of the nodes of this level.
 __global__ void __launch_bounds__(256) segPlan(uint32_t first, uint32_t count, const uint32_t* __restrict__ nBegin, const uint32_t* __restrict__ nEnd,
-                                               const uint32_t* __restrict__ nKeys, uint32_t* __restrict__ nAxis, double* __restrict__ nMid)
+                                               const uint32_t* __restrict__ nKeys, uint32_t* __restrict__ nAxis, double* __restrict__ nMid,
+                                               uint32_t leafBelow)
 {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= count) return;
     const uint32_t s = first + t;
-    if (nEnd[s] - nBegin[s] < kLeafBelow) { nAxis[s] = 3u; return; }
+    if (nEnd[s] - nBegin[s] < leafBelow) { nAxis[s] = 3u; return; }
     float lo[3], hi[3];
     for (int a = 0; a < 3; ++a) { lo[a] = fromKey(nKeys[(size_t)s * 6 + a]); hi[a] = fromKey(nKeys[(size_t)s * 6 + 3 + a]); }
     const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
@@ -344,8 +346,15 @@ __device__ inline NodeBox boxOf(uint32_t s, const uint32_t* nKeys, const uint32_
     return b;
 }
 
+// first leaf slot of a leaf: the reference numbers leaves right child first (n - end of the range), the sphere tree
+// left to right (begin of the range)
+__device__ inline uint32_t leafSlot(uint32_t s, uint32_t n, const uint32_t* nBegin, const uint32_t* nEnd, bool leftToRight)
+{
+    return leftToRight ? nBegin[s] : n - nEnd[s];
+}
+
 __device__ inline DevNodeRec recordOf(uint32_t s, uint32_t n, const uint32_t* nBegin, const uint32_t* nEnd, const uint32_t* nAxis,
-                                      const uint32_t* nKeys, const uint32_t* nZero, const uint32_t* pairOf)
+                                      const uint32_t* nKeys, const uint32_t* nZero, const uint32_t* pairOf, bool leftToRight)
 {
     DevNodeRec r;
     const NodeBox b = boxOf(s, nKeys, nZero);
@@ -356,7 +365,7 @@ __device__ inline DevNodeRec recordOf(uint32_t s, uint32_t n, const uint32_t* nB
     if (axis == 3u) {
         const uint32_t cnt = nEnd[s] - nBegin[s];
         r.num_prims = (uint8_t)cnt;
-        r.ref = kLeafBit | ((n - nEnd[s]) << 3) | cnt;
+        r.ref = kLeafBit | (leafSlot(s, n, nBegin, nEnd, leftToRight) << 3) | cnt;
     } else {
         r.num_prims = 0;
         r.ref = (axis << 29) | pairOf[s];
@@ -368,33 +377,35 @@ __device__ inline DevNodeRec recordOf(uint32_t s, uint32_t n, const uint32_t* nB
 __global__ void __launch_bounds__(256) emitNodes(uint32_t total, uint32_t n, const uint32_t* __restrict__ nBegin, const uint32_t* __restrict__ nEnd,
                                                  const uint32_t* __restrict__ nAxis, const uint32_t* __restrict__ nLeft, const uint32_t* __restrict__ nKeys,
                                                  const uint32_t* __restrict__ nZero, const uint32_t* __restrict__ pre, const uint32_t* __restrict__ pairOf,
-                                                 YartBvhNode* __restrict__ nodes, DevNodePair* __restrict__ pairs)
+                                                 YartBvhNode* __restrict__ nodes /* may be null */, DevNodePair* __restrict__ pairs, bool leftToRight)
 {
     const uint32_t s = blockIdx.x * 256u + threadIdx.x;
     if (s >= total) return;
-    const NodeBox b = boxOf(s, nKeys, nZero);
     const uint32_t axis = nAxis[s];
-    YartBvhNode nd;
-    for (int a = 0; a < 3; ++a) { nd.bounds_min[a] = b.lo[a]; nd.bounds_max[a] = b.hi[a]; }
-    nd.split_axis = (uint8_t)axis;
-    nd.pad[0] = nd.pad[1] = 0;
-    if (axis == 3u) {
-        nd.offset = n - nEnd[s];
-        nd.num_triangles = (uint8_t)(nEnd[s] - nBegin[s]);
-    } else {
-        nd.offset = pre[nLeft[s] + 1u];
-        nd.num_triangles = 0;
+    if (nodes) {
+        const NodeBox b = boxOf(s, nKeys, nZero);
+        YartBvhNode nd;
+        for (int a = 0; a < 3; ++a) { nd.bounds_min[a] = b.lo[a]; nd.bounds_max[a] = b.hi[a]; }
+        nd.split_axis = (uint8_t)axis;
+        nd.pad[0] = nd.pad[1] = 0;
+        if (axis == 3u) {
+            nd.offset = leafSlot(s, n, nBegin, nEnd, leftToRight);
+            nd.num_triangles = (uint8_t)(nEnd[s] - nBegin[s]);
+        } else {
+            nd.offset = pre[nLeft[s] + 1u];
+            nd.num_triangles = 0;
+        }
+        nodes[pre[s]] = nd;
     }
-    nodes[pre[s]] = nd;
     if (axis != 3u) {
         DevNodePair p;
-        p.child[0] = recordOf(nLeft[s], n, nBegin, nEnd, nAxis, nKeys, nZero, pairOf);
-        p.child[1] = recordOf(nLeft[s] + 1u, n, nBegin, nEnd, nAxis, nKeys, nZero, pairOf);
+        p.child[0] = recordOf(nLeft[s], n, nBegin, nEnd, nAxis, nKeys, nZero, pairOf, leftToRight);
+        p.child[1] = recordOf(nLeft[s] + 1u, n, nBegin, nEnd, nAxis, nKeys, nZero, pairOf, leftToRight);
         pairs[pairOf[s]] = p;
     }
     if (s == 0u) {
         DevNodePair p;
-        p.child[0] = recordOf(0u, n, nBegin, nEnd, nAxis, nKeys, nZero, pairOf);
+        p.child[0] = recordOf(0u, n, nBegin, nEnd, nAxis, nKeys, nZero, pairOf, leftToRight);
         DevNodeRec empty;
         for (int a = 0; a < 3; ++a) { empty.lo[a] = __builtin_inff(); empty.hi[a] = -__builtin_inff(); }
         empty.ref = kPadLeaf;
@@ -466,6 +477,42 @@ __global__ void __launch_bounds__(256) emitLeaves(const float4* __restrict__ rec
     triaccel[(size_t)slot * 3 + 2] = make_float4(o[8], o[9], o[10], o[11]);
 }
 
+// The engine's sphere tree (bvh_build.cpp buildSphereBvh): boxes widened by a relative margin so that the fp32 slab test
+// never rejects a ray the fp64 sphere test accepts, centre = the sphere's.  status[1]: a NaN (host builder's case).
+__global__ void __launch_bounds__(256) spherePrims(const float* __restrict__ spheres, uint32_t n, float4* __restrict__ primLo,
+                                                   float4* __restrict__ primHi, float4* __restrict__ rec, uint32_t* __restrict__ seg,
+                                                   uint32_t* __restrict__ status)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float* s = spheres + (size_t)i * 4;
+    const float r = fabsf(s[3]);
+    float lo[3], hi[3];
+    bool nan = !(r == r);
+    for (int a = 0; a < 3; ++a) {
+        const float margin = 1e-5f * (fabsf(s[a]) + r) + 1e-30f;
+        lo[a] = s[a] - r - margin;
+        hi[a] = s[a] + r + margin;
+        nan = nan || !(s[a] == s[a]) || !(lo[a] == lo[a]) || !(hi[a] == hi[a]);
+    }
+    if (nan) status[1] = 1u;
+    seg[i] = 0u;
+    primLo[i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+    primHi[i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+    rec[i] = make_float4(s[0], s[1], s[2], __uint_as_float(i));
+}
+
+// sphere records in leaf-slot order (= final position: leaves are numbered left to right) and the slot -> sphere table
+__global__ void __launch_bounds__(256) emitSphereLeaves(const float4* __restrict__ rec, uint32_t n, const float4* __restrict__ spheres,
+                                                        float4* __restrict__ records, uint32_t* __restrict__ index)
+{
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t id = __float_as_uint(rec[j].w);
+    records[j] = spheres[id];
+    index[j] = id;
+}
+
 struct Scratch {                    // frees whatever was allocated, whichever way the build ends
     std::vector<void*> ptrs;
     ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
@@ -488,6 +535,140 @@ void DeviceRefTree::release()
     nodes = pairs = triaccel = slotOfInput = nullptr;
 }
 
+namespace {
+
+// The level-synchronous partition build shared by the two trees: everything between "boxes, centres and the root are
+// set" and "nodes are numbered".
+struct Topology {
+    Scratch S;
+    uint32_t n = 0;
+    float4 *primLo = nullptr, *primHi = nullptr, *recA = nullptr, *recB = nullptr, *order = nullptr;
+    uint32_t *seg = nullptr, *leafOf = nullptr, *flags = nullptr, *T = nullptr, *failPos = nullptr, *passPos = nullptr, *counters = nullptr;
+    uint32_t *nBegin = nullptr, *nEnd = nullptr, *nKeys = nullptr, *nZero = nullptr, *nAxis = nullptr, *nSplit = nullptr, *nLeft = nullptr;
+    uint32_t *size = nullptr, *interior = nullptr, *pre = nullptr, *pairOf = nullptr;
+    double* nMid = nullptr;
+    OneSided* oneSided = nullptr;
+    char* scanTemp = nullptr;
+    size_t scanBytes = 0;
+    uint32_t total = 0, nInterior = 0;
+    int depth = 0;
+    size_t medianSplits = 0;
+
+    int allocate(size_t count, std::string& err)
+    {
+        n = static_cast<uint32_t>(count);
+        const size_t cap = 2 * count;                   // both children of a split hold at least one primitive
+        YART_HIP(S.alloc(&primLo, count));
+        YART_HIP(S.alloc(&primHi, count));
+        YART_HIP(S.alloc(&recA, count));
+        YART_HIP(S.alloc(&recB, count));
+        YART_HIP(S.alloc(&seg, count));
+        YART_HIP(S.alloc(&leafOf, count));
+        YART_HIP(S.alloc(&flags, count + 1));
+        YART_HIP(S.alloc(&T, count + 1));
+        YART_HIP(S.alloc(&failPos, count));
+        YART_HIP(S.alloc(&passPos, count));
+        YART_HIP(S.alloc(&counters, 64));
+        YART_HIP(S.alloc(&nBegin, cap));
+        YART_HIP(S.alloc(&nEnd, cap));
+        YART_HIP(S.alloc(&nKeys, cap * 6));
+        YART_HIP(S.alloc(&nZero, cap * 6));
+        YART_HIP(S.alloc(&nAxis, cap));
+        YART_HIP(S.alloc(&nSplit, cap));
+        YART_HIP(S.alloc(&nLeft, cap));
+        YART_HIP(S.alloc(&nMid, cap));
+        YART_HIP(S.alloc(&oneSided, kFixCap));
+        YART_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scanBytes, flags, T, (int)(count + 1), nullptr));
+        YART_HIP(S.alloc(&scanTemp, scanBytes));
+        const uint32_t initCounters[4] = { 1u, 0u, 0u, 0u };   // nodes, one-sided ranges, NaN records; words 8, 9: status
+        YART_HIP(hipMemcpyAsync(counters, initCounters, sizeof initCounters, hipMemcpyHostToDevice, nullptr));
+        YART_HIP(hipMemsetAsync(counters + 8, 0, 8, nullptr));
+        hipLaunchKernelGGL(initRoot, dim3(1), dim3(64), 0, nullptr, n, nBegin, nEnd, nKeys, nZero);
+        YART_HIP(hipGetLastError());
+        return YART_OK;
+    }
+
+    // primLo / primHi / recA / seg filled.  leafBelow: a range of fewer primitives is a leaf.
+    int run(uint32_t leafBelow, const char* what, bool* useHost, std::string& err)
+    {
+        std::vector<uint32_t> levelStart{ 0u };
+        uint32_t allocated = 1;
+        float4 *src = recA, *dst = recB;
+        std::vector<OneSided> ranges;
+        std::vector<float4> hostRecs, hostOut;
+        struct Item { float key; uint32_t idx; };
+        std::vector<Item> items;
+        for (;;) {
+            const uint32_t first = levelStart.back(), count = allocated - first;
+            if (static_cast<int>(levelStart.size()) > kMaxDepth) { err = std::string(what) + " BVH deeper than 64 levels"; return YART_ERR_TREE_TOO_DEEP; }
+            hipLaunchKernelGGL(segBounds, dim3(blocks(n, 1024)), dim3(1024), 0, nullptr, src, seg, n, primLo, primHi, nKeys, nZero);
+            hipLaunchKernelGGL(segPlan, dim3(blocks(count)), dim3(256), 0, nullptr, first, count, nBegin, nEnd, nKeys, nAxis, nMid, leafBelow);
+            hipLaunchKernelGGL(segFlags, dim3(blocks(size_t(n) + 1)), dim3(256), 0, nullptr, src, seg, n, nAxis, nMid, leafOf, flags);
+            YART_HIP(hipGetLastError());
+            YART_HIP(hipcub::DeviceScan::ExclusiveSum(scanTemp, scanBytes, flags, T, (int)(n + 1), nullptr));
+            hipLaunchKernelGGL(segSplit, dim3(blocks(count)), dim3(256), 0, nullptr, first, count, nBegin, nEnd, nAxis, T, nSplit, nLeft, nKeys, nZero,
+                               counters, oneSided);
+            YART_HIP(hipGetLastError());
+            uint32_t c[2];
+            YART_HIP(hipMemcpy(c, counters, sizeof c, hipMemcpyDeviceToHost));
+            levelStart.push_back(allocated);
+            if (c[0] == allocated) break;                    // every node of this level is a leaf
+            if (c[1]) {
+                // one-sided ranges: the same std::nth_element the host builder runs, on the same order of elements
+                medianSplits += c[1];
+                if (c[1] > kFixCap || medianSplits > 4 * static_cast<size_t>(kFixCap)) { *useHost = true; return YART_OK; }
+                ranges.resize(c[1]);
+                YART_HIP(hipMemcpy(ranges.data(), oneSided, c[1] * sizeof(OneSided), hipMemcpyDeviceToHost));
+                size_t elems = 0;
+                for (const OneSided& r : ranges) elems += r.end - r.begin;
+                if (elems > (size_t(1) << 24)) { *useHost = true; return YART_OK; }
+                for (const OneSided& r : ranges) {
+                    const size_t cnt = r.end - r.begin;
+                    hostRecs.resize(cnt);
+                    hostOut.resize(cnt);
+                    items.resize(cnt);
+                    YART_HIP(hipMemcpy(hostRecs.data(), src + r.begin, cnt * sizeof(float4), hipMemcpyDeviceToHost));
+                    for (size_t i = 0; i < cnt; ++i) {
+                        const float4& h = hostRecs[i];
+                        items[i] = Item{ r.axis == 0 ? h.x : (r.axis == 1 ? h.y : h.z), static_cast<uint32_t>(i) };
+                    }
+                    std::nth_element(items.begin(), items.begin() + cnt / 2, items.end(), [](const Item& a, const Item& b) { return a.key < b.key; });
+                    for (size_t i = 0; i < cnt; ++i) hostOut[i] = hostRecs[items[i].idx];
+                    YART_HIP(hipMemcpy(src + r.begin, hostOut.data(), cnt * sizeof(float4), hipMemcpyHostToDevice));
+                }
+                YART_HIP(hipMemsetAsync(counters + 1, 0, 4, nullptr));
+            }
+            hipLaunchKernelGGL(partners, dim3(blocks(n)), dim3(256), 0, nullptr, seg, n, nBegin, nEnd, nSplit, flags, T, failPos, passPos);
+            hipLaunchKernelGGL(applySplit, dim3(blocks(n)), dim3(256), 0, nullptr, src, dst, seg, n, nBegin, nEnd, nSplit, nLeft, flags, T, failPos, passPos);
+            YART_HIP(hipGetLastError());
+            std::swap(src, dst);
+            allocated = c[0];
+        }
+        order = src;
+        total = allocated;
+        depth = static_cast<int>(levelStart.size()) - 1;
+        if (total - 1 >= kMaxPairs) { err = "too many BVH nodes"; return YART_ERR_INVALID_ARGUMENT; }
+        // numbering: subtree sizes bottom-up, pre-order and pair numbers top-down
+        YART_HIP(S.alloc(&size, total));
+        YART_HIP(S.alloc(&interior, total));
+        YART_HIP(S.alloc(&pre, total));
+        YART_HIP(S.alloc(&pairOf, total));
+        for (int lv = depth - 1; lv >= 0; --lv) {
+            const uint32_t first = levelStart[lv], count = levelStart[lv + 1] - first;
+            hipLaunchKernelGGL(subtreeSizes, dim3(blocks(count)), dim3(256), 0, nullptr, first, count, nAxis, nLeft, size, interior);
+        }
+        for (int lv = 0; lv < depth; ++lv) {
+            const uint32_t first = levelStart[lv], count = levelStart[lv + 1] - first;
+            hipLaunchKernelGGL(numberNodes, dim3(blocks(count)), dim3(256), 0, nullptr, first, count, nAxis, nLeft, size, interior, pre, pairOf);
+        }
+        YART_HIP(hipGetLastError());
+        YART_HIP(hipMemcpy(&nInterior, interior, 4, hipMemcpyDeviceToHost));
+        return YART_OK;
+    }
+};
+
+} // namespace
+
 int buildReferenceTreeDevice(const float* dVerts, const float* verts, size_t nVerts, const int32_t* dTris, const int32_t* tris,
                              size_t nTris, DeviceRefTree& out, bool* useHost, std::string& err)
 {
@@ -495,145 +676,40 @@ int buildReferenceTreeDevice(const float* dVerts, const float* verts, size_t nVe
     *useHost = false;
     if (nTris < 1 || nTris >= kMaxLeafSlot) { *useHost = true; return YART_OK; }
     const auto t0 = std::chrono::steady_clock::now();
-    const uint32_t n = static_cast<uint32_t>(nTris);
-    const size_t cap = 2 * nTris;                       // both children of a split hold at least one triangle
-    Scratch S;
-    float4 *primLo, *primHi, *recA, *recB;
-    uint32_t *seg, *leafOf, *flags, *T, *failPos, *passPos, *counters;
-    uint32_t *nBegin, *nEnd, *nKeys, *nZero, *nAxis, *nSplit, *nLeft, *size, *interior, *pre, *pairOf;
-    double* nMid;
-    OneSided* oneSided;
+    Topology T;
+    int st = T.allocate(nTris, err);
+    if (st != YART_OK) return st;
+    const uint32_t n = T.n;
     NanFix* fixes;
-    YART_HIP(S.alloc(&primLo, nTris));
-    YART_HIP(S.alloc(&primHi, nTris));
-    YART_HIP(S.alloc(&recA, nTris));
-    YART_HIP(S.alloc(&recB, nTris));
-    YART_HIP(S.alloc(&seg, nTris));
-    YART_HIP(S.alloc(&leafOf, nTris));
-    YART_HIP(S.alloc(&flags, nTris + 1));
-    YART_HIP(S.alloc(&T, nTris + 1));
-    YART_HIP(S.alloc(&failPos, nTris));
-    YART_HIP(S.alloc(&passPos, nTris));
-    YART_HIP(S.alloc(&counters, 64));
-    YART_HIP(S.alloc(&nBegin, cap));
-    YART_HIP(S.alloc(&nEnd, cap));
-    YART_HIP(S.alloc(&nKeys, cap * 6));
-    YART_HIP(S.alloc(&nZero, cap * 6));
-    YART_HIP(S.alloc(&nAxis, cap));
-    YART_HIP(S.alloc(&nSplit, cap));
-    YART_HIP(S.alloc(&nLeft, cap));
-    YART_HIP(S.alloc(&nMid, cap));
-    YART_HIP(S.alloc(&oneSided, kFixCap));
-    YART_HIP(S.alloc(&fixes, kFixCap));
-    size_t scanBytes = 0;
-    YART_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scanBytes, flags, T, (int)(nTris + 1), nullptr));
-    char* scanTemp;
-    YART_HIP(S.alloc(&scanTemp, scanBytes));
-
-    const uint32_t initCounters[4] = { 1u, 0u, 0u, 0u };       // nodes, one-sided ranges, NaN records; then status words
-    YART_HIP(hipMemcpyAsync(counters, initCounters, sizeof initCounters, hipMemcpyHostToDevice, nullptr));
-    YART_HIP(hipMemsetAsync(counters + 8, 0, 8, nullptr));
-    hipLaunchKernelGGL(refPrims, dim3(blocks(nTris)), dim3(256), 0, nullptr, dVerts, dTris, n, (uint64_t)nVerts, primLo, primHi, recA, seg, counters + 8);
-    hipLaunchKernelGGL(initRoot, dim3(1), dim3(64), 0, nullptr, n, nBegin, nEnd, nKeys, nZero);
+    YART_HIP(T.S.alloc(&fixes, kFixCap));
+    hipLaunchKernelGGL(refPrims, dim3(blocks(nTris)), dim3(256), 0, nullptr, dVerts, dTris, n, (uint64_t)nVerts, T.primLo, T.primHi, T.recA, T.seg, T.counters + 8);
     YART_HIP(hipGetLastError());
     uint32_t status[2];
-    YART_HIP(hipMemcpy(status, counters + 8, sizeof status, hipMemcpyDeviceToHost));
+    YART_HIP(hipMemcpy(status, T.counters + 8, sizeof status, hipMemcpyDeviceToHost));
     if (status[0]) { err = "yart_accel_create: vertex index out of range"; return YART_ERR_INVALID_ARGUMENT; }
     if (status[1]) { *useHost = true; return YART_OK; }
-
-    std::vector<uint32_t> levelStart{ 0u };
-    uint32_t allocated = 1;
-    float4 *src = recA, *dst = recB;
-    std::vector<OneSided> ranges;
-    std::vector<float4> hostRecs, hostOut;
-    struct Item { float key; uint32_t idx; };
-    std::vector<Item> items;
-    for (;;) {
-        const uint32_t first = levelStart.back(), count = allocated - first;
-        if (static_cast<int>(levelStart.size()) > kMaxDepth) { err = "triangle BVH deeper than 64 levels"; return YART_ERR_TREE_TOO_DEEP; }
-        hipLaunchKernelGGL(segBounds, dim3(blocks(nTris, 1024)), dim3(1024), 0, nullptr, src, seg, n, primLo, primHi, nKeys, nZero);
-        hipLaunchKernelGGL(segPlan, dim3(blocks(count)), dim3(256), 0, nullptr, first, count, nBegin, nEnd, nKeys, nAxis, nMid);
-        hipLaunchKernelGGL(segFlags, dim3(blocks(nTris + 1)), dim3(256), 0, nullptr, src, seg, n, nAxis, nMid, leafOf, flags);
-        YART_HIP(hipGetLastError());
-        YART_HIP(hipcub::DeviceScan::ExclusiveSum(scanTemp, scanBytes, flags, T, (int)(nTris + 1), nullptr));
-        hipLaunchKernelGGL(segSplit, dim3(blocks(count)), dim3(256), 0, nullptr, first, count, nBegin, nEnd, nAxis, T, nSplit, nLeft, nKeys, nZero,
-                           counters, oneSided);
-        YART_HIP(hipGetLastError());
-        uint32_t c[2];
-        YART_HIP(hipMemcpy(c, counters, sizeof c, hipMemcpyDeviceToHost));
-        levelStart.push_back(allocated);
-        if (c[0] == allocated) break;                    // every node of this level is a leaf
-        if (c[1]) {
-            // one-sided ranges: the same std::nth_element the host builder runs, on the same order of elements
-            out.medianSplitsOnHost += c[1];
-            if (c[1] > kFixCap || out.medianSplitsOnHost > 4 * static_cast<size_t>(kFixCap)) { *useHost = true; return YART_OK; }
-            ranges.resize(c[1]);
-            YART_HIP(hipMemcpy(ranges.data(), oneSided, c[1] * sizeof(OneSided), hipMemcpyDeviceToHost));
-            size_t elems = 0;
-            for (const OneSided& r : ranges) elems += r.end - r.begin;
-            if (elems > (size_t(1) << 24)) { *useHost = true; return YART_OK; }
-            for (const OneSided& r : ranges) {
-                const size_t cnt = r.end - r.begin;
-                hostRecs.resize(cnt);
-                hostOut.resize(cnt);
-                items.resize(cnt);
-                YART_HIP(hipMemcpy(hostRecs.data(), src + r.begin, cnt * sizeof(float4), hipMemcpyDeviceToHost));
-                for (size_t i = 0; i < cnt; ++i) {
-                    const float4& h = hostRecs[i];
-                    items[i] = Item{ r.axis == 0 ? h.x : (r.axis == 1 ? h.y : h.z), static_cast<uint32_t>(i) };
-                }
-                std::nth_element(items.begin(), items.begin() + cnt / 2, items.end(), [](const Item& a, const Item& b) { return a.key < b.key; });
-                for (size_t i = 0; i < cnt; ++i) hostOut[i] = hostRecs[items[i].idx];
-                YART_HIP(hipMemcpy(src + r.begin, hostOut.data(), cnt * sizeof(float4), hipMemcpyHostToDevice));
-            }
-            YART_HIP(hipMemsetAsync(counters + 1, 0, 4, nullptr));
-        }
-        hipLaunchKernelGGL(partners, dim3(blocks(nTris)), dim3(256), 0, nullptr, seg, n, nBegin, nEnd, nSplit, flags, T, failPos, passPos);
-        hipLaunchKernelGGL(applySplit, dim3(blocks(nTris)), dim3(256), 0, nullptr, src, dst, seg, n, nBegin, nEnd, nSplit, nLeft, flags, T, failPos, passPos);
-        YART_HIP(hipGetLastError());
-        std::swap(src, dst);
-        allocated = c[0];
-    }
-    const uint32_t total = allocated;
-    const int depth = static_cast<int>(levelStart.size()) - 1;
-    if (total - 1 >= kMaxPairs) { err = "too many BVH nodes"; return YART_ERR_INVALID_ARGUMENT; }
-
-    // numbering
-    YART_HIP(S.alloc(&size, total));
-    YART_HIP(S.alloc(&interior, total));
-    YART_HIP(S.alloc(&pre, total));
-    YART_HIP(S.alloc(&pairOf, total));
-    for (int lv = depth - 1; lv >= 0; --lv) {
-        const uint32_t first = levelStart[lv], count = levelStart[lv + 1] - first;
-        hipLaunchKernelGGL(subtreeSizes, dim3(blocks(count)), dim3(256), 0, nullptr, first, count, nAxis, nLeft, size, interior);
-    }
-    for (int lv = 0; lv < depth; ++lv) {
-        const uint32_t first = levelStart[lv], count = levelStart[lv + 1] - first;
-        hipLaunchKernelGGL(numberNodes, dim3(blocks(count)), dim3(256), 0, nullptr, first, count, nAxis, nLeft, size, interior, pre, pairOf);
-    }
-    YART_HIP(hipGetLastError());
-    uint32_t nInterior = 0;
-    YART_HIP(hipMemcpy(&nInterior, interior, 4, hipMemcpyDeviceToHost));
+    st = T.run(kLeafBelow, "triangle", useHost, err);
+    if (st != YART_OK || *useHost) return st;
 
     // the arrays the caller keeps
     DeviceRefTree r;
-    r.numNodes = total;
-    r.numPairs = static_cast<size_t>(nInterior) + 1;
+    r.numNodes = T.total;
+    r.numPairs = static_cast<size_t>(T.nInterior) + 1;
     r.numTriangles = nTris;
-    r.depth = depth;
+    r.depth = T.depth;
     hipError_t e = hipMalloc(&r.nodes, r.numNodes * sizeof(YartBvhNode));
     if (e == hipSuccess) e = hipMalloc(&r.pairs, r.numPairs * sizeof(DevNodePair));
     if (e == hipSuccess) e = hipMalloc(&r.triaccel, nTris * sizeof(YartTriAccel));
     if (e == hipSuccess) e = hipMalloc(&r.slotOfInput, nTris * sizeof(uint32_t));
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(emitNodes, dim3(blocks(total)), dim3(256), 0, nullptr, total, n, nBegin, nEnd, nAxis, nLeft, nKeys, nZero, pre, pairOf,
-                           static_cast<YartBvhNode*>(r.nodes), static_cast<DevNodePair*>(r.pairs));
-        hipLaunchKernelGGL(emitLeaves, dim3(blocks(nTris)), dim3(256), 0, nullptr, src, leafOf, n, nBegin, nEnd, dVerts, dTris,
-                           static_cast<uint32_t*>(r.slotOfInput), static_cast<float4*>(r.triaccel), counters, fixes);
+        hipLaunchKernelGGL(emitNodes, dim3(blocks(T.total)), dim3(256), 0, nullptr, T.total, n, T.nBegin, T.nEnd, T.nAxis, T.nLeft, T.nKeys, T.nZero, T.pre, T.pairOf,
+                           static_cast<YartBvhNode*>(r.nodes), static_cast<DevNodePair*>(r.pairs), false);
+        hipLaunchKernelGGL(emitLeaves, dim3(blocks(nTris)), dim3(256), 0, nullptr, T.order, T.leafOf, n, T.nBegin, T.nEnd, dVerts, dTris,
+                           static_cast<uint32_t*>(r.slotOfInput), static_cast<float4*>(r.triaccel), T.counters, fixes);
         e = hipGetLastError();
     }
     uint32_t nFix = 0;
-    if (e == hipSuccess) e = hipMemcpy(&nFix, counters + 2, 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&nFix, T.counters + 2, 4, hipMemcpyDeviceToHost);
     DevNodePair rootPair;
     if (e == hipSuccess) e = hipMemcpy(&rootPair, r.pairs, sizeof rootPair, hipMemcpyDeviceToHost);
     if (e == hipSuccess && nFix > kFixCap) { r.release(); *useHost = true; return YART_OK; }
@@ -657,7 +733,60 @@ int buildReferenceTreeDevice(const float* dVerts, const float* verts, size_t nVe
     }
     std::memcpy(r.rootLo, rootPair.child[0].lo, 12);
     std::memcpy(r.rootHi, rootPair.child[0].hi, 12);
-    r.medianSplitsOnHost = out.medianSplitsOnHost;
+    r.medianSplitsOnHost = T.medianSplits;
+    r.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    out = r;
+    return YART_OK;
+}
+
+void DeviceSphereTree::release()
+{
+    (void)hipFree(pairs); (void)hipFree(records); (void)hipFree(index);
+    pairs = records = index = nullptr;
+}
+
+int buildSphereTreeDevice(const float* dSpheres, size_t nSpheres, DeviceSphereTree& out, bool* useHost, std::string& err)
+{
+    out = DeviceSphereTree{};
+    *useHost = false;
+    if (nSpheres < 1 || nSpheres >= kMaxLeafSlot) { *useHost = true; return YART_OK; }
+    const auto t0 = std::chrono::steady_clock::now();
+    Topology T;
+    int st = T.allocate(nSpheres, err);
+    if (st != YART_OK) return st;
+    const uint32_t n = T.n;
+    hipLaunchKernelGGL(spherePrims, dim3(blocks(nSpheres)), dim3(256), 0, nullptr, dSpheres, n, T.primLo, T.primHi, T.recA, T.seg, T.counters + 8);
+    YART_HIP(hipGetLastError());
+    uint32_t status[2];
+    YART_HIP(hipMemcpy(status, T.counters + 8, sizeof status, hipMemcpyDeviceToHost));
+    if (status[1]) { *useHost = true; return YART_OK; }
+    st = T.run(kSphereLeafBelow, "sphere", useHost, err);
+    if (st != YART_OK || *useHost) return st;
+
+    DeviceSphereTree r;
+    r.numPairs = static_cast<size_t>(T.nInterior) + 1;
+    r.numSpheres = nSpheres;
+    r.depth = T.depth;
+    hipError_t e = hipMalloc(&r.pairs, r.numPairs * sizeof(DevNodePair));
+    if (e == hipSuccess) e = hipMalloc(&r.records, nSpheres * 16);
+    if (e == hipSuccess) e = hipMalloc(&r.index, nSpheres * 4);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(emitNodes, dim3(blocks(T.total)), dim3(256), 0, nullptr, T.total, n, T.nBegin, T.nEnd, T.nAxis, T.nLeft, T.nKeys, T.nZero, T.pre, T.pairOf,
+                           static_cast<YartBvhNode*>(nullptr), static_cast<DevNodePair*>(r.pairs), true);
+        hipLaunchKernelGGL(emitSphereLeaves, dim3(blocks(nSpheres)), dim3(256), 0, nullptr, T.order, n, reinterpret_cast<const float4*>(dSpheres),
+                           static_cast<float4*>(r.records), static_cast<uint32_t*>(r.index));
+        e = hipGetLastError();
+    }
+    DevNodePair rootPair;
+    if (e == hipSuccess) e = hipMemcpy(&rootPair, r.pairs, sizeof rootPair, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        r.release();
+        err = std::string("device sphere-tree build: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? YART_ERR_OUT_OF_MEMORY : YART_ERR_HIP;
+    }
+    std::memcpy(r.rootLo, rootPair.child[0].lo, 12);
+    std::memcpy(r.rootHi, rootPair.child[0].hi, 12);
     r.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     out = r;
     return YART_OK;

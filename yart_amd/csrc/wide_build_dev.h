@@ -34,6 +34,7 @@ public:
     // The scene as topology() uploaded it; valid until finish() or destruction (ref_build_dev.hip reads it).
     const float* deviceVerts() const;
     const int32_t* deviceTris() const;
+    const float* deviceSpheres() const;
 
 private:
     struct State;

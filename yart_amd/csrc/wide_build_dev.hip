@@ -838,6 +838,7 @@ int DeviceWideBuilder::topology(const float* verts, size_t nVerts, const int32_t
 // Phase 2: what needs the reference's leaf order -- the leaf rows -- and the exact-size result arrays.
 const float* DeviceWideBuilder::deviceVerts() const { return state_ ? state_->dVerts : nullptr; }
 const int32_t* DeviceWideBuilder::deviceTris() const { return state_ ? state_->dTris : nullptr; }
+const float* DeviceWideBuilder::deviceSpheres() const { return state_ ? state_->dSpheres : nullptr; }
 
 int DeviceWideBuilder::finish(const void* dTriAccel, const uint32_t* slotOfInput, bool slotsOnDevice, DeviceWide& out, std::string& err)
 {
