@@ -134,6 +134,28 @@ def test_seeded_scenes_against_reference_rule(n_tris, n_sph, s):
     assert np.array_equal(bits(got["t"]), bits(want["t"]))
 
 
+def test_ill_conditioned_slivers_stay_within_the_stated_exception():
+    """DESIGN.md section 1, third exception: slivers a thousand times the size of the rest make Wald's test accept
+    points outside the triangle, and which of those a traversal meets depends on its boxes.  The default walk may then
+    differ from the reference -- by a bounded share of the rays; the pruned walk over the reference's own boxes
+    (oracle mode 1, what YART_REFERENCE_TREE runs) still returns the reference's answer on every ray."""
+    worst = 0.0
+    for seed in (0, 2):
+        v, t, sph = scenes.random_soup(5000, 3000, s=0.01, seed=seed + 10)
+        rng = np.random.RandomState(seed)
+        v = v.copy()
+        v[rng.rand(len(v)) < 0.001] *= 1000.0
+        rays = scenes.random_rays(20000, seed=seed + 1)
+        o = orc.Oracle(v, t, sph)
+        want = o.intersect(rays, mode=0)
+        pruned = o.intersect(rays, mode=1)
+        assert np.array_equal(pruned["prim"], want["prim"]) and np.array_equal(bits(pruned["t"]), bits(want["t"]))
+        nodes, rows_a, rows_bc, _ = api.build_wide_host(v, t, sph)
+        got = orc.wide_intersect(nodes, rows_a, rows_bc, rays)
+        worst = max(worst, float((got["prim"] != want["prim"]).mean()))
+    assert 0.0 < worst <= 0.005          # present (else the exception can be struck from DESIGN.md), and small
+
+
 def test_degenerate_inputs_build():
     """NaN / infinite coordinates and identical primitives must not break the build."""
     v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [np.nan, 0, 0], [1, 1, 1], [2, 2, 2],
