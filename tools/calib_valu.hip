@@ -70,6 +70,14 @@ __global__ void __launch_bounds__(256) valu(float* out, uint64_t* cycles, float 
 #pragma unroll
             for (int i = 0; i < kUnroll / 2; ++i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pm), "v"(pa));
         }
+        if (KIND == 36) {
+#pragma unroll
+            for (int i = 0; i < kUnroll / 2; ++i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[1,0,0] clamp" : "+v"(p[i]) : "v"(pm), "v"(pa));
+        }
+        if (KIND == 37) {
+#pragma unroll
+            for (int i = 0; i < kUnroll / 2; ++i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[1,0,0]" : "+v"(p[i]) : "v"(pm), "v"(pa));
+        }
         if (KIND == 23) {
 #pragma unroll
             for (int i = 0; i < kUnroll / 2; ++i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pm));
@@ -152,6 +160,8 @@ int main()
         run<34>("v_add_u32", kUnroll, b, out, dCycles, numCUs);
         run<35>("v_add_u32_sdwa byte1", kUnroll, b, out, dCycles, numCUs);
         run<4>("v_pk_fma_f32", kUnroll / 2, b, out, dCycles, numCUs);
+        run<37>("v_pk_fma_f32 op_sel_hi:[1,0,0]", kUnroll / 2, b, out, dCycles, numCUs);
+        run<36>("v_pk_fma_f32 op_sel_hi clamp", kUnroll / 2, b, out, dCycles, numCUs);
         run<23>("v_pk_mul_f32", kUnroll / 2, b, out, dCycles, numCUs);
         run<24>("v_pk_add_f32", kUnroll / 2, b, out, dCycles, numCUs);
     }
