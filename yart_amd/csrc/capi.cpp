@@ -213,7 +213,7 @@ int runIntersect(YartAccel* a, const Launch& L, const CallScratch* given)
         W.deferFlag = W.workCounter + 1;
         W.deferList = slot0 + 256;                  // behind the four counter slots (accel.h: kCounterBlockBytes)
         W.deferCap = yart::kDeferCap;
-        W.refillMin = a->wideRefillMin; W.nodeMin = a->wideNodeMin; W.chunk = a->wideChunk; W.maxBlocksPerCU = a->wideBlocksPerCU;
+        W.refillMin = a->wideRefillMin; W.nodeMin = a->wideNodeMin; W.sphereMin = a->wideSphereMin; W.chunk = a->wideChunk; W.maxBlocksPerCU = a->wideBlocksPerCU;
         for (int c = 0; c < 3; ++c) { W.sceneLo[c] = a->sceneLo[c]; W.sceneHi[c] = a->sceneHi[c]; }
         {
             ScopedSpan span(a, 2, L.stream);
@@ -292,6 +292,9 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
     if (const char* v = std::getenv("YART_WIDE_NODE_MIN")) a->wideNodeMin = static_cast<uint32_t>(std::atoi(v));
     if (a->wideNodeMin < 1) a->wideNodeMin = 1;
     if (a->wideNodeMin > 64) a->wideNodeMin = 64;
+    if (const char* v = std::getenv("YART_WIDE_SPHERE_MIN")) a->wideSphereMin = static_cast<uint32_t>(std::atoi(v));
+    if (a->wideSphereMin < 1) a->wideSphereMin = 1;
+    if (a->wideSphereMin > 64) a->wideSphereMin = 64;
     if (const char* v = std::getenv("YART_SORT_GRID_BITS")) a->sortGridBits = static_cast<uint32_t>(std::atoi(v));
     if (const char* v = std::getenv("YART_SORT_MIN_RAYS")) a->sortMinRays = static_cast<uint32_t>(std::strtoul(v, nullptr, 10));
     if (const char* v = std::getenv("YART_SORT_OCT_SHIFT")) a->sortOctShift = static_cast<uint32_t>(std::atoi(v));

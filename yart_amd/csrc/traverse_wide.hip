@@ -153,7 +153,7 @@ __device__ __forceinline__ float hitScale(float t)
     }
 
 template <bool ANY, bool COUNT, bool PERSIST>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) traceWide(WideParams P)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 8))) traceWide(WideParams P)
 {
     __shared__ uint32_t ldsStack[kLdsStack * kBlock];
     uint32_t ovf[kOvfStack];
@@ -165,7 +165,9 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
     WRay r;
     r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = r.tmax = 0.0f;
     uint32_t cur = kIdle;
-    uint32_t pend = kIdle;                         // a leaf set aside while the lane keeps descending
+    uint32_t pend = kIdle;                         // a triangle leaf set aside while the lane keeps descending
+    uint32_t pendS = kIdle;                        // a sphere leaf set aside likewise: the sphere test is double-precision code
+                                                   // of its own, run only once enough lanes hold one (sphereMin)
     int sp = 0;
     bool live = false;
     uint32_t rayId = 0;
@@ -177,7 +179,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
     uint32_t occ = 0;
     uint32_t cNodes = 0, cTri = 0, cSph = 0, cStage2 = 0;
 #ifdef YART_STEP_STATS
-    uint32_t stNodeSteps = 0, stNodeLanes = 0, stLeafSteps = 0, stLeafLanes = 0, stIters = 0, stLive = 0;
+    uint32_t stNodeSteps = 0, stNodeLanes = 0, stLeafSteps = 0, stLeafLanes = 0, stIters = 0, stLive = 0, stSphSteps = 0, stSphLanes = 0;
 #endif
 
     uint32_t chunkNext = 0, chunkEnd = 0;
@@ -187,6 +189,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
     uint32_t rangesDone = 0;
     const int refillMin = (int)P.refillMin;
     const int nodeMin = (int)P.nodeMin;
+    const int sphereMin = (int)P.sphereMin;
     const uint32_t kChunk = P.chunk;             // rays a wave takes from a range counter at a time
 
     auto push = [&](uint32_t v) {
@@ -233,6 +236,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
         sp = 0;
         live = true;
         pend = kIdle;
+        pendS = kIdle;
         cur = 0u;                                  // root node
     };
 
@@ -272,16 +276,30 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
         }
 
         // ------------------------------------------------------------ descend
-        // Speculative descent: a lane that reaches a leaf sets it aside (one per lane) and goes on
+        // Speculative descent: a lane that reaches a leaf sets it aside (one of each kind per lane) and goes on
         // with the next node of its stack instead of idling until the wave turns to the leaves; the
         // leaf is tested in the next leaf phase.  Nodes visited meanwhile are tested against a bound
         // that does not yet know that leaf's hit -- a little extra work for lanes that stay busy.
+        // A triangle leaf and a sphere leaf are set aside in slots of their own: a lane that holds one of a kind is
+        // stopped only by a second leaf of the same kind (with one slot for both, 5.01 -> 4.78 ms on C4).  The sphere
+        // leaves wait until sphereMin lanes hold one, unless a lane cannot go on without (its next node is another
+        // sphere leaf) or the wave has no interior node left; the threshold matters little (1..24: within 0.3 %), and
+        // letting lanes wait for it without that exception costs more than the fuller sphere steps save.
+        bool sphNow = false;
         for (;;) {
-            if (pend == kIdle && cur != kIdle && cur != kNeedPop && (cur & kPackLeaf)) { pend = cur; cur = kNeedPop; }
+            if ((cur & kPackLeaf) && cur < kNeedPop) {              // a leaf (the two markers are the largest values)
+                if (cur & kPackSphere) { if (pendS == kIdle) { pendS = cur; cur = kNeedPop; } }
+                else if (pend == kIdle) { pend = cur; cur = kNeedPop; }
+            }
             if (cur == kNeedPop) cur = pop();
             const uint64_t inner = __ballot((cur & kPackLeaf) == 0);
-            if (inner == 0) break;
-            if (__popcll(inner) < nodeMin && __ballot(pend != kIdle) != 0) break;
+            if (inner == 0) { sphNow = true; break; }
+            if (__popcll(inner) < nodeMin) {
+                const uint64_t sphHeld = __ballot(pendS != kIdle);
+                sphNow = sphHeld != 0 && (__popcll(sphHeld) >= sphereMin ||
+                                          __ballot((cur & kPackLeaf) && cur < kNeedPop && (cur & kPackSphere)) != 0);
+                if (sphNow || __ballot(pend != kIdle) != 0) break;
+            }
 #ifdef YART_STEP_STATS
             ++stNodeSteps; stNodeLanes += __popcll(inner);
 #endif
@@ -316,14 +334,15 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
 
         // ------------------------------------------------------------ leaf
 #ifdef YART_STEP_STATS
-        { const uint64_t pm = __ballot(pend != kIdle); if (pm) { ++stLeafSteps; stLeafLanes += __popcll(pm); } ++stIters; stLive += __popcll(__ballot(live)); }
+        { const uint64_t pm = __ballot(pend != kIdle); if (pm) { ++stLeafSteps; stLeafLanes += __popcll(pm); } ++stIters; stLive += __popcll(__ballot(live));
+          const uint64_t sm = __ballot(sphNow && pendS != kIdle); if (sm) { ++stSphSteps; stSphLanes += __popcll(sm); } }
 #endif
+        bool stop = false;
         if (pend != kIdle) {
             const uint32_t leaf = pend;
             pend = kIdle;
             const float4* row = P.units + (leaf >> 2);          // one primitive per leaf
-            bool stop = false;
-            if ((leaf & kPackSphere) == 0) {
+            {
                 do {
                     const float4 A = row[0];
                     if (COUNT) ++cTri;
@@ -359,7 +378,12 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
                     primTri = (int32_t)(kw >> 2);
                     invB = hitScale(t);                    // t is below the bound, or ties with it
                 } while (false);
-            } else {
+            }
+        }
+        if (sphNow && pendS != kIdle && !stop) {
+            const float4* row = P.units + (pendS >> 2);
+            pendS = kIdle;
+            {
                 do {
                     const float4 S = row[0];
                     if (COUNT) ++cSph;
@@ -388,11 +412,11 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
                     }
                 } while (false);
             }
-            if (stop) { cur = kIdle; sp = 0; }
         }
+        if (stop) { cur = kIdle; sp = 0; pend = kIdle; pendS = kIdle; }
 
         // ------------------------------------------------------------ retire
-        if (cur == kIdle && pend == kIdle && live) {
+        if (cur == kIdle && pend == kIdle && pendS == kIdle && live) {
             live = false;
             if (ANY) {
                 P.occluded[rayId] = (uint8_t)occ;
@@ -417,6 +441,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
         atomicAdd(P.workCounter + 9, stNodeSteps); atomicAdd(P.workCounter + 10, stNodeLanes >> 6);
         atomicAdd(P.workCounter + 11, stLeafSteps); atomicAdd(P.workCounter + 12, stLeafLanes >> 6);
         atomicAdd(P.workCounter + 13, stIters); atomicAdd(P.workCounter + 14, stLive >> 6);
+        atomicAdd(P.workCounter + 17, stSphSteps); atomicAdd(P.workCounter + 18, stSphLanes);
     }
 #endif
 }
@@ -446,10 +471,11 @@ hipError_t launchW(const WideParams& P, bool persistent, int numCUs, hipStream_t
         if (grid > needBlocks) grid = needBlocks;
         hipLaunchKernelGGL((traceWide<ANY, COUNT, true>), dim3(grid), dim3(kBlock), 0, stream, P);
 #ifdef YART_STEP_STATS
-        uint32_t st[8];
-        if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(st + 2, P.workCounter + 9, 6 * 4, hipMemcpyDeviceToHost) == hipSuccess && P.n > 1000000)
-            fprintf(stderr, "step stats (%u rays, any=%d): node steps %u, mean lanes %.1f; leaf steps %u, mean lanes %.1f; outer iterations %u, mean live lanes %.1f\n",
-                    P.n, (int)ANY, st[2], 64.0 * st[3] / (st[2] ? st[2] : 1), st[4], 64.0 * st[5] / (st[4] ? st[4] : 1), st[6], 64.0 * st[7] / (st[6] ? st[6] : 1));
+        uint32_t st[12];
+        if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(st + 2, P.workCounter + 9, 10 * 4, hipMemcpyDeviceToHost) == hipSuccess && P.n > 1000000)
+            fprintf(stderr, "step stats (%u rays, any=%d): node steps %u, mean lanes %.1f; triangle leaf steps %u, mean lanes %.1f; sphere leaf steps %u, mean lanes %.1f; outer iterations %u, mean live lanes %.1f\n",
+                    P.n, (int)ANY, st[2], 64.0 * st[3] / (st[2] ? st[2] : 1), st[4], 64.0 * st[5] / (st[4] ? st[4] : 1), st[10], (double)st[11] / (st[10] ? st[10] : 1),
+                    st[6], 64.0 * st[7] / (st[6] ? st[6] : 1));
 #endif
     } else {
         const uint32_t grid = (P.n + kBlock - 1) / kBlock;
