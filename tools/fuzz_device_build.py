@@ -67,7 +67,9 @@ for it in range(rounds):
     ok = res["1"][0] == res["0"][0] and res["1"][1] == res["0"][1]
     # reference-tree rules: same tree, same kernels -> identical; default rule: another wide tree -> same prim & t (ties aside)
     ok = ok and all(np.array_equal(x.view(np.int32), y.view(np.int32)) for x, y in zip(res["1"][2][2:], res["0"][2][2:]))
-    ok = ok and all(np.array_equal(x, y) for x, y in zip(res["1"][3], res["0"][3]))
+    # any-hit: the reference rule must agree exactly; the default rule too, the ill-conditioned slivers of kind 3 aside
+    ok = ok and np.array_equal(res["1"][3][1], res["0"][3][1])
+    ok = ok and (res["1"][3][0] != res["0"][3][0]).mean() <= (0.01 if kind == 3 else 0.0)
     # The default rule against the pruned rule on the reference's tree: the parity bar.  kind 3 holds sliver triangles a
     # thousand times the size of the rest, whose Wald test accepts points within float error OUTSIDE the triangle; which
     # of those a traversal meets depends on its boxes (third exception), so the bar is relaxed there.
