@@ -453,48 +453,24 @@ bool traverseWide(const WideNodeRec* nodes, const float* rowsA, const float* row
     uint32_t stack[128];
     int sp = 0;
     uint32_t cur = 0;
-    // 1 / (what nodes are culled against), as traverse_wide.hip cullScale -- a hair larger than the kernel's
-    // (whose reciprocal is the hardware's approximate one), so that this walk never visits a node the kernel culls:
-    // the tests hold the kernel's fetch counts against this walk's from below.
-    auto cullScale = [](float best) {
-        return (1.0f / std::fmin(std::fmax(best * kCullSlack, 0x1p-30f), 0x1p96f)) * (1.0f + 0x1p-21f);
-    };
-    float invB;
-    {
-        // before there is a hit: twice the largest distance to a plane of the scene's box (here: the root node's)
-        float m = 0.0f;
-        for (int a = 0; a < 3; ++a) {
-            float lo = inf, hi = -inf;
-            for (int ch = 0; ch < 4; ++ch) {
-                if (nodes[0].ref[ch] == kNone) continue;
-                lo = std::fmin(lo, nodes[0].origin[a] + (float)nodes[0].qlo[a][ch] * nodes[0].scale[a]);
-                hi = std::fmax(hi, nodes[0].origin[a] + (float)nodes[0].qhi[a][ch] * nodes[0].scale[a]);
-            }
-            m = std::fmax(m, std::fmax(std::fabs((lo - r.o[a]) * inv[a]), std::fabs((hi - r.o[a]) * inv[a])));
-        }
-        invB = cullScale(fmin2(r.tmax, 2.0f * m));
-    }
     for (;;) {
         if (!(cur & kLeaf)) {
             const WideNodeRec& n = nodes[cur];
             if (c) c->nodes += 4;
-            // as traverse_wide.hip slab4: box distances in units of the cull bound, entry planes clamped to [0, 1]
-            // (NaN -> 0, as the hardware's clamp), exit planes not; an entry of 1 is a child at or beyond the bound
+            const float bound = (shadow ? r.tmax : fmin2(tTri, F)) * kCullSlack;     // as traverse_wide.hip
             float tn[4];
             uint32_t rf[4];
             int nHit = 0;
             for (int ch = 0; ch < 4; ++ch) {
-                float tNear = 0.0f, tFar = inf;
+                float tNear = 0.0f, tFar = bound;
                 for (int a = 0; a < 3; ++a) {
-                    const float k = inv[a] * invB;
-                    const float A = (n.origin[a] - r.o[a]) * k, B = n.scale[a] * k;
+                    const float A = (n.origin[a] - r.o[a]) * inv[a], B = n.scale[a] * inv[a];
                     const bool neg = inv[a] < 0.0f;
                     const float qn = (float)(neg ? n.qhi[a][ch] : n.qlo[a][ch]), qf = (float)(neg ? n.qlo[a][ch] : n.qhi[a][ch]);
-                    const float e = std::fma(qn, B, A);
-                    tNear = std::fmax(tNear, e != e ? 0.0f : std::fmin(std::fmax(e, 0.0f), 1.0f));
+                    tNear = std::fmax(tNear, std::fma(qn, B, A));
                     tFar = std::fmin(tFar, std::fma(qf, B, A));
                 }
-                const bool h = !(tFar < tNear) && tNear < 1.0f && n.ref[ch] != kNone;
+                const bool h = !(tFar < tNear) && tNear < inf && n.ref[ch] != kNone;     // as traverse_wide.hip slab4 + its +inf marker
                 tn[ch] = h ? tNear : inf;
                 rf[ch] = n.ref[ch];
                 nHit += h ? 1 : 0;
@@ -522,7 +498,6 @@ bool traverseWide(const WideNodeRec* nodes, const float* rowsA, const float* row
                     if (wald(ta, r, t, u, v)) {
                         if (shadow) return true;
                         tTri = t; hu = u; hv = v; primTri = slot;
-                        invB = cullScale(t);
                     } else if (!shadow && primTri >= 0 && slot < primTri) {
                         // exact-t tie: the lower leaf slot wins (see traverse_wide.hip)
                         float t2 = std::nextafter(tTri, inf);
@@ -546,7 +521,7 @@ bool traverseWide(const WideNodeRec* nodes, const float* rowsA, const float* row
                     std::memcpy(&idxBits, BC, 4);
                     const int32_t idx = (int32_t)idxBits;
                     const bool below = t < (double)f;
-                    if (minS < 0 || f < F) { F = f; minS = idx; maxL = below ? idx : -1; invB = cullScale(f); }
+                    if (minS < 0 || f < F) { F = f; minS = idx; maxL = below ? idx : -1; }
                     else { minS = std::min(minS, idx); if (below && idx > maxL) maxL = idx; }
                 }
             }

@@ -78,6 +78,18 @@ __global__ void __launch_bounds__(256) valu(float* out, uint64_t* cycles, float 
 #pragma unroll
             for (int i = 0; i < kUnroll / 2; ++i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[1,0,0]" : "+v"(p[i]) : "v"(pm), "v"(pa));
         }
+        if (KIND >= 40 && KIND <= 47) {
+            // operand classes: does the packed fma (with and without clamp) slow down on denormal, huge or NaN values?
+            const float x = KIND == 40 ? 3.0f : KIND == 41 ? -3.0f : KIND == 42 ? 1e-41f : KIND == 43 ? 1e30f :
+                            KIND == 44 ? __builtin_inff() : KIND == 45 ? __builtin_nanf("") : KIND == 46 ? 1e-41f : 0.25f;
+            const f32x2 src = { x * seed, x * seed };
+            const f32x2 one = { seed, seed }, zero = { 0.0f, 0.0f };
+#pragma unroll
+            for (int i = 0; i < kUnroll / 2; ++i) {
+                if (KIND == 46) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(p[i]) : "v"(src), "v"(one), "v"(zero));
+                else asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0] clamp" : "=v"(p[i]) : "v"(src), "v"(one), "v"(zero));
+            }
+        }
         if (KIND == 23) {
 #pragma unroll
             for (int i = 0; i < kUnroll / 2; ++i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pm));
@@ -162,6 +174,14 @@ int main()
         run<4>("v_pk_fma_f32", kUnroll / 2, b, out, dCycles, numCUs);
         run<37>("v_pk_fma_f32 op_sel_hi:[1,0,0]", kUnroll / 2, b, out, dCycles, numCUs);
         run<36>("v_pk_fma_f32 op_sel_hi clamp", kUnroll / 2, b, out, dCycles, numCUs);
+        run<47>("pk_fma clamp, value 0.25", kUnroll / 2, b, out, dCycles, numCUs);
+        run<40>("pk_fma clamp, value 3 (clamped)", kUnroll / 2, b, out, dCycles, numCUs);
+        run<41>("pk_fma clamp, value -3 (clamped)", kUnroll / 2, b, out, dCycles, numCUs);
+        run<42>("pk_fma clamp, denormal", kUnroll / 2, b, out, dCycles, numCUs);
+        run<46>("pk_fma no clamp, denormal", kUnroll / 2, b, out, dCycles, numCUs);
+        run<43>("pk_fma clamp, 1e30", kUnroll / 2, b, out, dCycles, numCUs);
+        run<44>("pk_fma clamp, inf", kUnroll / 2, b, out, dCycles, numCUs);
+        run<45>("pk_fma clamp, NaN", kUnroll / 2, b, out, dCycles, numCUs);
         run<23>("v_pk_mul_f32", kUnroll / 2, b, out, dCycles, numCUs);
         run<24>("v_pk_add_f32", kUnroll / 2, b, out, dCycles, numCUs);
     }

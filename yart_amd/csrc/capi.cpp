@@ -214,7 +214,6 @@ int runIntersect(YartAccel* a, const Launch& L, const CallScratch* given)
         W.deferList = slot0 + 256;                  // behind the four counter slots (accel.h: kCounterBlockBytes)
         W.deferCap = yart::kDeferCap;
         W.refillMin = a->wideRefillMin; W.nodeMin = a->wideNodeMin; W.sphereMin = a->wideSphereMin; W.chunk = a->wideChunk; W.maxBlocksPerCU = a->wideBlocksPerCU;
-        for (int c = 0; c < 3; ++c) { W.sceneLo[c] = a->sceneLo[c]; W.sceneHi[c] = a->sceneHi[c]; }
         {
             ScopedSpan span(a, 2, L.stream);
             e = yart::launchTraceWide(W, L.any, L.count, persistent, a->numCUs, L.stream);

@@ -64,8 +64,6 @@ struct WideParams {
     uint32_t sphereMin;         // sphere leaves are tested once this many lanes of a wave hold one
     uint32_t maxBlocksPerCU;    // 0 = as many as fit (8)
     uint32_t chunk;             // rays a wave takes from its range counter at a time (multiple of 64)
-    float sceneLo[3], sceneHi[3];   // bounds of every primitive: how far along a ray anything can be (the scale of a ray's box
-                                    // distances before it has a hit)
 };
 
 hipError_t launchTraceWide(const WideParams& P, bool any, bool count, bool persistent, int numCUs,

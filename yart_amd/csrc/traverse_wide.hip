@@ -66,82 +66,50 @@ struct WRay {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// Packed fma, both halves of b and a being their low half; Clamp: the result clamped to [0, 1] (the VOP3P clamp bit).
-__device__ __forceinline__ f32x2 pkFmaClamp(f32x2 q, float b, float a)
-{
-    f32x2 out, bb, aa;
-    bb.x = b; aa.x = a;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0] clamp" : "=v"(out) : "v"(q), "v"(bb), "v"(aa));
-    return out;
-}
-__device__ __forceinline__ f32x2 pkFma(f32x2 q, float b, float a)
-{
-    f32x2 out, bb, aa;
-    bb.x = b; aa.x = a;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(out) : "v"(q), "v"(bb), "v"(aa));
-    return out;
-}
-
-// Slab test of the four child boxes of a node against [0, bound] (minT is 0 for every ray this kernel takes), in
-// units of the bound: invB = 1 / bound (cullScale).  Per axis the distance to grid plane q is t(q) / bound = A + q * B
-// with A = (origin - o) / d / bound, B = step / d / bound.  The ENTRY planes' fma clamps its result to [0, 1]: that is
-// the max with 0 of the interval test, and an entry at or beyond the bound comes out as exactly 1, which the caller
-// reads as "missed" -- so neither a max with 0 nor a min with the bound is issued per child.  The exit planes are
-// not clamped: a box behind the origin exits below 0 <= entry and fails the test; a box of no thickness has entry ==
-// exit (same operands, same fma) and passes it.  The sign of d says which of a child's two planes is the entry
-// plane, so the packed plane dwords are swapped once per node instead of taking a min and a max per child and axis.
-// Two children share one packed fma (v_pk_fma_f32).  The boxes are the engine's own (quantised, conservative), so
-// this arithmetic is free to use fma; the primitive tests are what has to round like the reference.
-// tn[c] = entry distance / bound in [0, 1]; h[c]: entry <= exit (the caller still has to reject tn[c] == 1).
+// Slab test of the four child boxes of a node against [0, bound] (minT is 0 for every ray this
+// kernel takes).  Per axis the distance to grid plane q is t(q) = A + q * B with A = (origin - o) / d,
+// B = scale / d; the sign of d says which of a child's two planes is the entry plane, so the packed
+// plane dwords are swapped once per node instead of taking a min and a max per child and axis.
+// Two children share one packed fma (v_pk_fma_f32).  The boxes are the engine's own (quantised,
+// conservative), so this arithmetic is free to use fma; the primitive tests are what has to round
+// like the reference.  tn[c] = entry distance, returns hit flags in h[c].
 __device__ __forceinline__ void slab4(const float4& q0, const float4& q1, const float4& q2, const WRay& r,
-                                      float invB, float tn[4], bool h[4])
+                                      float bound, float tn[4], bool h[4])
 {
     const uint32_t steps = __float_as_uint(q0.w);
     const float sx = __uint_as_float(steps & kStepMask), sy = __uint_as_float((steps << 10) & kStepMask),
                 sz = __uint_as_float((steps << 20) & kStepMask);
-    const float kx = r.ix * invB, ky = r.iy * invB, kz = r.iz * invB;
-    const float Ax = (q0.x - r.ox) * kx, Bx = sx * kx;
-    const float Ay = (q0.y - r.oy) * ky, By = sy * ky;
-    const float Az = (q0.z - r.oz) * kz, Bz = sz * kz;
+    const float Ax = (q0.x - r.ox) * r.ix, Bx = sx * r.ix;
+    const float Ay = (q0.y - r.oy) * r.iy, By = sy * r.iy;
+    const float Az = (q0.z - r.oz) * r.iz, Bz = sz * r.iz;
     const uint32_t lx = __float_as_uint(q1.x), ly = __float_as_uint(q1.y), lz = __float_as_uint(q1.z);
     const uint32_t hx = __float_as_uint(q1.w), hy = __float_as_uint(q2.x), hz = __float_as_uint(q2.y);
     const bool negx = r.ix < 0.0f, negy = r.iy < 0.0f, negz = r.iz < 0.0f;
     const uint32_t nx = negx ? hx : lx, fx = negx ? lx : hx;      // byte c = entry / exit plane of child c
     const uint32_t ny = negy ? hy : ly, fy = negy ? ly : hy;
     const uint32_t nz = negz ? hz : lz, fz = negz ? lz : hz;
+    const f32x2 ax = { Ax, Ax }, bx = { Bx, Bx }, ay = { Ay, Ay }, by = { By, By }, az = { Az, Az }, bz = { Bz, Bz };
 #define YART_PAIR(w, s) (f32x2){ (float)(((w) >> (s)) & 255u), (float)(((w) >> ((s) + 8)) & 255u) }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        const f32x2 tnx = pkFmaClamp(YART_PAIR(nx, 16 * p), Bx, Ax);
-        const f32x2 tny = pkFmaClamp(YART_PAIR(ny, 16 * p), By, Ay);
-        const f32x2 tnz = pkFmaClamp(YART_PAIR(nz, 16 * p), Bz, Az);
-        const f32x2 tfx = pkFma(YART_PAIR(fx, 16 * p), Bx, Ax);
-        const f32x2 tfy = pkFma(YART_PAIR(fy, 16 * p), By, Ay);
-        const f32x2 tfz = pkFma(YART_PAIR(fz, 16 * p), Bz, Az);
+        const f32x2 tnx = __builtin_elementwise_fma(YART_PAIR(nx, 16 * p), bx, ax);
+        const f32x2 tny = __builtin_elementwise_fma(YART_PAIR(ny, 16 * p), by, ay);
+        const f32x2 tnz = __builtin_elementwise_fma(YART_PAIR(nz, 16 * p), bz, az);
+        const f32x2 tfx = __builtin_elementwise_fma(YART_PAIR(fx, 16 * p), bx, ax);
+        const f32x2 tfy = __builtin_elementwise_fma(YART_PAIR(fy, 16 * p), by, ay);
+        const f32x2 tfz = __builtin_elementwise_fma(YART_PAIR(fz, 16 * p), bz, az);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const float tNear = fmaxf(fmaxf(tnx[e], tny[e]), tnz[e]);
-            const float tFar = fminf(fminf(tfx[e], tfy[e]), tfz[e]);
+            const float tNear = fmaxf(fmaxf(tnx[e], tny[e]), fmaxf(tnz[e], 0.0f));
+            const float tFar = fminf(fminf(tfx[e], tfy[e]), fminf(tfz[e], bound));
             tn[2 * p + e] = tNear;
+            // tNear >= 0 and tFar <= bound <= tmax, neither can be NaN (0 and bound are operands), so this
+            // differs from the full interval test only for a box that ends exactly at the origin or begins
+            // exactly at tmax: visiting those is harmless, no primitive test can accept there
             h[2 * p + e] = !(tFar < tNear);
         }
     }
 #undef YART_PAIR
-}
-
-// 1 / (what nodes are culled against): the best hit so far times kCullSlack, kept inside [2^-30, 2^96] so that the
-// scaled plane coefficients neither overflow nor vanish (a wider bound only culls less; a scene box with infinite
-// planes takes the upper end).
-__device__ __forceinline__ float cullScale(float best)
-{
-    return __builtin_amdgcn_rcpf(fminf(fmaxf(best * kCullSlack, 0x1p-30f), 0x1p96f));
-}
-
-// The same for an accepted hit: its t lies in (1e-4, tmax), so the lower end needs no guard; beyond 2^126 the
-// reciprocal is 0, every box distance with it, and nothing is culled.
-__device__ __forceinline__ float hitScale(float t)
-{
-    return __builtin_amdgcn_rcpf(t * kCullSlack);
 }
 
 #define YART_CSWAP(i, j)                                                   \
@@ -175,7 +143,6 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
     int32_t primTri = -1;
     float F = 0.0f;                                // best sphere: float t, candidates bookkeeping
     int32_t minS = -1, maxL = -1;
-    float invB = 0.0f;                             // 1 / the bound nodes are culled against (cullScale)
     uint32_t occ = 0;
     uint32_t cNodes = 0, cTri = 0, cSph = 0, cStage2 = 0;
 #ifdef YART_STEP_STATS
@@ -223,15 +190,6 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
         r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
         tTri = r.tmax; hu = 0.0f; hv = 0.0f; primTri = -1;
         F = __builtin_inff(); minS = -1; maxL = -1; occ = 0;
-        {
-            // Until there is a hit, nodes are "culled" against twice the largest distance at which the ray meets a
-            // plane of the scene's box (nothing lies beyond the farthest of them, the factor two is far more than
-            // the planes' rounding): not to cull anything, but to give the box distances a scale (slab4).
-            const float m = fmaxf(fmaxf(fmaxf(__builtin_fabsf((P.sceneLo[0] - r.ox) * r.ix), __builtin_fabsf((P.sceneHi[0] - r.ox) * r.ix)),
-                                        fmaxf(__builtin_fabsf((P.sceneLo[1] - r.oy) * r.iy), __builtin_fabsf((P.sceneHi[1] - r.oy) * r.iy))),
-                                  fmaxf(__builtin_fabsf((P.sceneLo[2] - r.oz) * r.iz), __builtin_fabsf((P.sceneHi[2] - r.oz) * r.iz)));
-            invB = cullScale(fminf(r.tmax, 2.0f * m));
-        }
         cNodes = 0; cTri = 0; cSph = 0; cStage2 = 0;
         sp = 0;
         live = true;
@@ -307,27 +265,28 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
                 // three 16-byte requests per visit: the child references are one block address and four byte offsets
                 const float4* p = P.units + (cur >> 2);
                 const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+                const float bound = (ANY ? r.tmax : fminf(tTri, F)) * kCullSlack;
                 float tn[4];
                 uint32_t rf[4];
                 const uint32_t blk = __float_as_uint(q2.z), offs = __float_as_uint(q2.w);
                 rf[0] = blk + (offs & 255u); rf[1] = blk + ((offs >> 8) & 255u);
                 rf[2] = blk + ((offs >> 16) & 255u); rf[3] = blk + (offs >> 24);
                 bool h[4];
-                slab4(q0, q1, q2, r, invB, tn, h);
+                slab4(q0, q1, q2, r, bound, tn, h);
                 // an unused slot needs no test of its own: its box is inverted on every axis (qlo 255, qhi 0:
                 // wide_build.cpp clear()), so it exits before it enters
                 if (COUNT) cNodes += 4;
                 {
-                    // nearest child next, the others pushed far to near; +inf marks the missed ones and sorts them last
+                    // nearest child next, the others pushed far to near.  A hit child has tn < tmax, so
+                    // +inf marks the missed ones and sorts them last.
                     const float inf = __builtin_inff();
 #pragma unroll
                     for (int c = 0; c < 4; ++c) tn[c] = h[c] ? tn[c] : inf;
                     YART_CSWAP(0, 1) YART_CSWAP(2, 3) YART_CSWAP(0, 2) YART_CSWAP(1, 3) YART_CSWAP(1, 2)
-                    // an entry distance of 1 (in units of the bound) is a child at or beyond the bound: missed, too
-                    if (tn[3] < 1.0f) push(rf[3]);
-                    if (tn[2] < 1.0f) push(rf[2]);
-                    if (tn[1] < 1.0f) push(rf[1]);
-                    cur = (tn[0] < 1.0f) ? rf[0] : kNeedPop;
+                    if (tn[3] < inf) push(rf[3]);
+                    if (tn[2] < inf) push(rf[2]);
+                    if (tn[1] < inf) push(rf[1]);
+                    cur = (tn[0] < inf) ? rf[0] : kNeedPop;
                 }
             }
         }
@@ -376,7 +335,6 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
                     if (ANY) { occ = 1; stop = true; break; }
                     tTri = t; hv = lambda; hu = mue;       // include/triaccel.h:194-196
                     primTri = (int32_t)(kw >> 2);
-                    invB = hitScale(t);                    // t is below the bound, or ties with it
                 } while (false);
             }
         }
@@ -405,7 +363,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
                     const int32_t idx = (int32_t)__float_as_uint(row[1].x);
                     if (COUNT) ++cStage2;
                     const bool below = t < (double)f;
-                    if (minS < 0 || f < F) { F = f; minS = idx; maxL = below ? idx : -1; invB = hitScale(f); }
+                    if (minS < 0 || f < F) { F = f; minS = idx; maxL = below ? idx : -1; }
                     else {
                         minS = (idx < minS) ? idx : minS;
                         if (below && idx > maxL) maxL = idx;
