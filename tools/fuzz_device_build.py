@@ -9,12 +9,14 @@ from yart_amd import api, scenes
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+only = int(sys.argv[3]) if len(sys.argv) > 3 else -1          # run just this round (the others only draw their random numbers)
 bad = 0
 for it in range(rounds):
     n_tris = int(rng.choice([0, 3, 900, 1024, 1500, 5000, 40000, 262144 - 100, 270000, 600000]))
     n_sph = int(rng.choice([0, 1, 50, 1023, 1024, 3000, 60000]))
     kind = rng.randint(4)
     if kind == 0 or n_tris < 1000:
+        kind = 0        # rays stay in the unit cube: spheres of radius 1e-3 seen from 10 units away are ill conditioned
         v, t, s = scenes.random_soup(n_tris, n_sph, s=float(rng.choice([0.002, 0.02, 0.2])), seed=int(rng.randint(1 << 30)))
     elif kind == 1:
         v, t, _ = scenes.architectural(max(n_tris, 2000), seed=int(rng.randint(1 << 30)))
@@ -35,6 +37,10 @@ for it in range(rounds):
         rays[:, :3] = rays[:, :3] * 14 - 7
     rays[::97, 4] = 0.0                     # some axis-parallel ones for the fix-up path
     shadow = rays.copy(); shadow[:, 7] = float(rng.choice([0.3, 3.0]))
+    if only >= 0 and it != only:
+        continue
+    if only >= 0:
+        np.savez("gpurun_out/fuzz_round_%d.npz" % it, verts=v, tris=t, spheres=s, rays=rays, shadow=shadow)
     res = {}
     failed = {}
     for mode in ("1", "0"):
@@ -85,5 +91,7 @@ for it in range(rounds):
     print("round %2d kind %d tris %7d spheres %6d device-built wide=%s ref=%s median ranges %d nan records %d: %s"
           % (it, kind, len(t), len(s), res["1"][4], res["1"][5][0], res["1"][5][2], res["1"][5][3], "ok" if ok else "MISMATCH " + "; ".join(why)), flush=True)
     bad += 0 if ok else 1
+    if only >= 0:
+        np.savez("gpurun_out/fuzz_round_%d_results.npz" % it, **{"closest_%s_%d" % (m, k): x for m in ("1", "0") for k, x in enumerate(res[m][2])})
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
