@@ -5,6 +5,8 @@ the bench's rays, every one of them traced by the GPU (default rule and referenc
 oracle's restatement of the reference on the host cores.  Prints one JSON line.
 
     python tests/parity_at_scale.py [log2_rays]
+    python tests/parity_at_scale.py 18 1000000 100000      # with spheres: tris, spheres (same local density as configs[3];
+                                                           # the oracle loops over all spheres per ray like the reference)
 """
 import json
 import os
@@ -20,8 +22,11 @@ from oracle import oracle as orc  # noqa: E402
 from yart_amd import api, scenes  # noqa: E402
 
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 22
-verts, tris, _ = scenes.random_soup(10_000_000, 0, s=0.005, seed=42)
-sph = np.zeros((0, 4), np.float32)
+n_tris = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
+n_sph = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+# fewer primitives in the same cube: larger ones, so that a ray meets as many of them (0.005 at 10 M triangles)
+scale = 0.005 * (10_000_000 / n_tris) ** (1.0 / 3.0)
+verts, tris, sph = scenes.random_soup(n_tris, n_sph, s=scale, seed=42)
 rays = scenes.random_rays(1 << lg, seed=7)
 acc = api.Accel(verts, tris, sph)
 d = torch.from_numpy(rays).cuda()
@@ -34,7 +39,7 @@ t1 = time.time()
 want = o.intersect(rays, mode=0, nthreads=threads)
 t2 = time.time()
 hit = want["prim"] != -1
-out = {"scene": "10 M-triangle soup, s=0.005", "rays": 1 << lg, "hits": int(hit.sum()),
+out = {"scene": "%d-triangle soup + %d spheres, s=%.4f" % (n_tris, n_sph, scale), "rays": 1 << lg, "hits": int(hit.sum()),
        "reference_rule": {"same_prim": float((exact["prim"] == want["prim"]).mean()),
                           "t_bits_equal": float((exact["t"].view(np.uint32) == want["t"].view(np.uint32)).mean()),
                           "uv_bits_equal": float(((exact["u"].view(np.uint32) == want["u"].view(np.uint32)) &
