@@ -54,7 +54,7 @@ struct YartAccel {
     uint64_t profiledCalls = 0;
     // scheduling knobs of the persistent kernel (YART_REFILL_MIN / YART_NODE_MIN override)
     uint32_t refillMin = 16, nodeMin = 24;                    // reference-tree kernels
-    uint32_t wideRefillMin = 16, wideNodeMin = 40, wideSphereMin = 8, wideChunk = 64, wideBlocksPerCU = 0;   // wide-tree kernel
+    uint32_t wideRefillMin = 16, wideNodeMin = 40, wideSphereMin = 8, wideChunk = 64, wideBlocksPerCU = 0, wideLaneCap = 0;   // wide-tree kernel
     uint32_t sortMinRays = 3u << 19;   // below ~1.5 M rays the sort costs more than it saves (profiles/r01_batch_sweep.jsonl)
     uint32_t sortOctShift = 0, sortGridBits = 7;      // 7: 24-bit keys = 3 radix passes; finer grids measured no better
     // Small host-buffer calls (the one-ray-per-call pattern of the reference's renderer,

@@ -213,7 +213,7 @@ int runIntersect(YartAccel* a, const Launch& L, const CallScratch* given)
         W.deferFlag = W.workCounter + 1;
         W.deferList = slot0 + 256;                  // behind the four counter slots (accel.h: kCounterBlockBytes)
         W.deferCap = yart::kDeferCap;
-        W.refillMin = a->wideRefillMin; W.nodeMin = a->wideNodeMin; W.sphereMin = a->wideSphereMin; W.chunk = a->wideChunk; W.maxBlocksPerCU = a->wideBlocksPerCU;
+        W.refillMin = a->wideRefillMin; W.nodeMin = a->wideNodeMin; W.sphereMin = a->wideSphereMin; W.chunk = a->wideChunk; W.maxBlocksPerCU = a->wideBlocksPerCU; W.laneCap = a->wideLaneCap;
         {
             ScopedSpan span(a, 2, L.stream);
             e = yart::launchTraceWide(W, L.any, L.count, persistent, a->numCUs, L.stream);
@@ -298,6 +298,7 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
     if (const char* v = std::getenv("YART_SORT_MIN_RAYS")) a->sortMinRays = static_cast<uint32_t>(std::strtoul(v, nullptr, 10));
     if (const char* v = std::getenv("YART_SORT_OCT_SHIFT")) a->sortOctShift = static_cast<uint32_t>(std::atoi(v));
     if (const char* v = std::getenv("YART_WIDE_BLOCKS_PER_CU")) a->wideBlocksPerCU = static_cast<uint32_t>(std::atoi(v));
+    if (const char* v = std::getenv("YART_WIDE_LANE_CAP")) a->wideLaneCap = static_cast<uint32_t>(std::atoi(v));
     if (const char* v = std::getenv("YART_WIDE_CHUNK")) a->wideChunk = static_cast<uint32_t>(std::atoi(v));
     a->wideChunk = (a->wideChunk + 63) / 64 * 64;
     if (a->wideChunk < 64) a->wideChunk = 64;

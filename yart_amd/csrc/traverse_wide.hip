@@ -158,6 +158,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
     const int nodeMin = (int)P.nodeMin;
     const int sphereMin = (int)P.sphereMin;
     const uint32_t kChunk = P.chunk;             // rays a wave takes from a range counter at a time
+    const uint64_t capMask = (P.laneCap == 0 || P.laneCap >= 64) ? ~0ull : ((1ull << P.laneCap) - 1ull);
 
     auto push = [&](uint32_t v) {
         if (sp < kLdsStack) ldsStack[sp * kBlock + tid] = v;
@@ -201,9 +202,9 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
     for (;;) {
         // ------------------------------------------------------------ fetch work
         if (PERSIST) {
-            const uint64_t idleMask = __ballot(!live);
+            const uint64_t idleMask = __ballot(!live) & capMask;
             const int nIdle = __popcll(idleMask);
-            if (!exhausted && (nIdle >= refillMin || idleMask == ~0ull)) {
+            if (!exhausted && (nIdle >= refillMin || idleMask == capMask)) {
                 while (chunkNext == chunkEnd && !exhausted) {
                     const uint32_t range = (homeXcd + rangesDone) & 7u;
                     const uint32_t rBegin = rangeBegin(P.n, range, kChunk), rEnd = rangeBegin(P.n, range + 1, kChunk);
@@ -424,10 +425,21 @@ hipError_t launchW(const WideParams& P, bool persistent, int numCUs, hipStream_t
         if (P.maxBlocksPerCU) want = (int)P.maxBlocksPerCU;
         if (perCU > want) perCU = want;
         uint32_t grid = (uint32_t)numCUs * (uint32_t)perCU;
-        const uint32_t need = (P.n + P.chunk - 1) / P.chunk;
+        // A batch of a few thousand rays is latency bound -- its time is that of the wave whose rays take the most steps --
+        // so it is spread over more waves that fill only 16 or 32 of their lanes: 2^12 rays 0.171 -> 0.136 ms, 2^14 rays
+        // 0.258 -> 0.237 ms; from 2^16 rays up full waves are faster (YART_WIDE_LANE_CAP overrides, 64 = never).
+        WideParams Q = P;
+        if (Q.laneCap == 0) Q.laneCap = P.n <= 8192u ? 16u : P.n <= 32768u ? 32u : 64u;
+        if (Q.laneCap > 0 && Q.laneCap < 64) {
+            Q.chunk = Q.laneCap;
+            Q.refillMin = Q.refillMin * Q.laneCap / 64 ? Q.refillMin * Q.laneCap / 64 : 1;
+            Q.nodeMin = Q.nodeMin * Q.laneCap / 64 ? Q.nodeMin * Q.laneCap / 64 : 1;
+            Q.sphereMin = Q.sphereMin * Q.laneCap / 64 ? Q.sphereMin * Q.laneCap / 64 : 1;
+        }
+        const uint32_t need = (Q.n + Q.chunk - 1) / Q.chunk;
         const uint32_t needBlocks = (need + 3) / 4;
         if (grid > needBlocks) grid = needBlocks;
-        hipLaunchKernelGGL((traceWide<ANY, COUNT, true>), dim3(grid), dim3(kBlock), 0, stream, P);
+        hipLaunchKernelGGL((traceWide<ANY, COUNT, true>), dim3(grid), dim3(kBlock), 0, stream, Q);
 #ifdef YART_STEP_STATS
         uint32_t st[12];
         if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(st + 2, P.workCounter + 9, 10 * 4, hipMemcpyDeviceToHost) == hipSuccess && P.n > 1000000)
