@@ -392,7 +392,12 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
                 int32_t prim = sphere ? -((minS > maxL ? minS : maxL) + 2) : primTri;
                 if (!(t < r.tmax)) prim = -1;
                 if (sphere || prim == -1) { hu = 0.0f; hv = 0.0f; }
-                P.hits[rayId] = make_float4(t, hu, hv, __int_as_float(prim));
+                {
+                    // written once, read by the caller: a streaming store (C4 -1.2 %; the loads are another matter)
+                    typedef float f32x4 __attribute__((ext_vector_type(4)));
+                    const f32x4 h4 = { t, hu, hv, __int_as_float(prim) };
+                    __builtin_nontemporal_store(h4, reinterpret_cast<f32x4*>(P.hits + rayId));
+                }
             }
             if (COUNT) {
                 uint32_t* c = P.counts + (size_t)rayId * 4;
