@@ -213,7 +213,7 @@ int runIntersect(YartAccel* a, const Launch& L, const CallScratch* given)
         W.deferFlag = W.workCounter + 1;
         W.deferList = slot0 + 256;                  // behind the four counter slots (accel.h: kCounterBlockBytes)
         W.deferCap = yart::kDeferCap;
-        W.refillMin = a->wideRefillMin; W.nodeMin = a->wideNodeMin; W.sphereMin = a->wideSphereMin; W.chunk = a->wideChunk; W.maxBlocksPerCU = a->wideBlocksPerCU; W.laneCap = a->wideLaneCap;
+        W.refillMin = a->wideRefillMin; W.nodeMin = a->wideNodeMin; W.sphereMin = a->wideSphereMin; W.chunk = a->wideChunk; W.maxBlocksPerCU = a->wideBlocksPerCU; W.laneCap = a->wideLaneCap; W.hasSpheres = a->numSpheres > 0 ? 1u : 0u;
         {
             ScopedSpan span(a, 2, L.stream);
             e = yart::launchTraceWide(W, L.any, L.count, persistent, a->numCUs, L.stream);

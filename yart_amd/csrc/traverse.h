@@ -62,6 +62,7 @@ struct WideParams {
     uint32_t refillMin;
     uint32_t nodeMin;
     uint32_t sphereMin;         // sphere leaves are tested once this many lanes of a wave hold one
+    uint32_t hasSpheres;        // 0: a tree of triangle leaves only (the kernel instance without the sphere side)
     uint32_t laneCap;           // lanes of a wave that take rays (0 or 64: all): small batches spread over more, emptier waves
     uint32_t maxBlocksPerCU;    // 0 = as many as fit (8)
     uint32_t chunk;             // rays a wave takes from its range counter at a time (multiple of 64)

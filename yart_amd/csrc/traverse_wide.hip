@@ -120,7 +120,9 @@ __device__ __forceinline__ void slab4(const float4& q0, const float4& q1, const 
         tn[i] = tf_; tn[j] = tg_; rf[i] = rf_; rf[j] = rg_;                \
     }
 
-template <bool ANY, bool COUNT, bool PERSIST>
+// SPH: the tree holds sphere leaves.  A scene of triangles only runs an instance without the sphere slot, the sphere
+// test and the sphere side of the bookkeeping.
+template <bool ANY, bool COUNT, bool PERSIST, bool SPH>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 8))) traceWide(WideParams P)
 {
     __shared__ uint32_t ldsStack[kLdsStack * kBlock];
@@ -247,15 +249,15 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
         bool sphNow = false;
         for (;;) {
             if ((cur & kPackLeaf) && cur < kNeedPop) {              // a leaf (the two markers are the largest values)
-                if (cur & kPackSphere) { if (pendS == kIdle) { pendS = cur; cur = kNeedPop; } }
+                if (SPH && (cur & kPackSphere)) { if (pendS == kIdle) { pendS = cur; cur = kNeedPop; } }
                 else if (pend == kIdle) { pend = cur; cur = kNeedPop; }
             }
             if (cur == kNeedPop) cur = pop();
             const uint64_t inner = __ballot((cur & kPackLeaf) == 0);
             if (inner == 0) { sphNow = true; break; }
             if (__popcll(inner) < nodeMin) {
-                const uint64_t sphHeld = __ballot(pendS != kIdle);
-                sphNow = sphHeld != 0 && (__popcll(sphHeld) >= sphereMin ||
+                const uint64_t sphHeld = SPH ? __ballot(pendS != kIdle) : 0ull;
+                sphNow = SPH && sphHeld != 0 && (__popcll(sphHeld) >= sphereMin ||
                                           __ballot((cur & kPackLeaf) && cur < kNeedPop && (cur & kPackSphere)) != 0);
                 if (sphNow || __ballot(pend != kIdle) != 0) break;
             }
@@ -271,7 +273,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
                 // latency starts earlier.  C4 4.77 -> 4.68 ms, s = 0.01 7.81 -> 7.50 ms; the level (1..3) does not
                 // matter, and lowering it for the primitive tests as well gives half of that back.
                 __builtin_amdgcn_s_setprio(0);
-                const float bound = (ANY ? r.tmax : fminf(tTri, F)) * kCullSlack;
+                const float bound = (ANY ? r.tmax : (SPH ? fminf(tTri, F) : tTri)) * kCullSlack;
                 float tn[4];
                 uint32_t rf[4];
                 const uint32_t blk = __float_as_uint(q2.z), offs = __float_as_uint(q2.w);
@@ -321,7 +323,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
                                 ov = sel3(k, r.oz, r.ox, r.oy);
                     const float nd = 1.0f / (dk + A.x * du + A.y * dv);
                     const float t = (A.z - ok - A.x * ou - A.y * ov) * nd;
-                    const float bound = ANY ? r.tmax : fminf(tTri, F);
+                    const float bound = ANY ? r.tmax : (SPH ? fminf(tTri, F) : tTri);
                     // The reference keeps the FIRST triangle it finds at a given t (`info->t > t` is
                     // strict); coplanar duplicates sit in one of its leaves in slot order, so the lowest
                     // slot wins there.  An exact tie therefore goes to the lower slot here, whatever
@@ -345,7 +347,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
                 } while (false);
             }
         }
-        if (sphNow && pendS != kIdle && !stop) {
+        if (SPH && sphNow && pendS != kIdle && !stop) {
             const float4* row = P.units + (pendS >> 2);
             pendS = kIdle;
             {
@@ -381,13 +383,13 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
         if (stop) { cur = kIdle; sp = 0; pend = kIdle; pendS = kIdle; }
 
         // ------------------------------------------------------------ retire
-        if (cur == kIdle && pend == kIdle && pendS == kIdle && live) {
+        if (cur == kIdle && pend == kIdle && (!SPH || pendS == kIdle) && live) {
             live = false;
             if (ANY) {
                 P.occluded[rayId] = (uint8_t)occ;
             } else {
                 // include/scene.h:142-167: spheres first, a triangle replaces the sphere only if strictly closer
-                const bool sphere = (minS >= 0) && !(tTri < F);
+                const bool sphere = SPH && (minS >= 0) && !(tTri < F);
                 float t = sphere ? F : tTri;
                 int32_t prim = sphere ? -((minS > maxL ? minS : maxL) + 2) : primTri;
                 if (!(t < r.tmax)) prim = -1;
@@ -416,7 +418,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
 #endif
 }
 
-template <bool ANY, bool COUNT>
+template <bool ANY, bool COUNT, bool SPH>
 hipError_t launchW(const WideParams& P, bool persistent, int numCUs, hipStream_t stream)
 {
     if (P.n == 0) return hipSuccess;
@@ -424,7 +426,7 @@ hipError_t launchW(const WideParams& P, bool persistent, int numCUs, hipStream_t
     if (e != hipSuccess) return e;
     if (persistent) {
         int perCU = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, traceWide<ANY, COUNT, true>, kBlock, 0);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, traceWide<ANY, COUNT, true, SPH>, kBlock, 0);
         if (e != hipSuccess) return e;
         if (perCU < 1) perCU = 1;
         if (perCU > 8) perCU = 8;
@@ -450,7 +452,7 @@ hipError_t launchW(const WideParams& P, bool persistent, int numCUs, hipStream_t
         const uint32_t need = (Q.n + Q.chunk - 1) / Q.chunk;
         const uint32_t needBlocks = (need + 3) / 4;
         if (grid > needBlocks) grid = needBlocks;
-        hipLaunchKernelGGL((traceWide<ANY, COUNT, true>), dim3(grid), dim3(kBlock), 0, stream, Q);
+        hipLaunchKernelGGL((traceWide<ANY, COUNT, true, SPH>), dim3(grid), dim3(kBlock), 0, stream, Q);
 #ifdef YART_STEP_STATS
         uint32_t st[12];
         if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(st + 2, P.workCounter + 9, 10 * 4, hipMemcpyDeviceToHost) == hipSuccess && P.n > 1000000)
@@ -460,7 +462,7 @@ hipError_t launchW(const WideParams& P, bool persistent, int numCUs, hipStream_t
 #endif
     } else {
         const uint32_t grid = (P.n + kBlock - 1) / kBlock;
-        hipLaunchKernelGGL((traceWide<ANY, COUNT, false>), dim3(grid), dim3(kBlock), 0, stream, P);
+        hipLaunchKernelGGL((traceWide<ANY, COUNT, false, SPH>), dim3(grid), dim3(kBlock), 0, stream, P);
     }
     return hipGetLastError();
 }
@@ -470,8 +472,12 @@ hipError_t launchW(const WideParams& P, bool persistent, int numCUs, hipStream_t
 hipError_t launchTraceWide(const WideParams& P, bool any, bool count, bool persistent, int numCUs,
                            hipStream_t stream)
 {
-    if (any) return count ? launchW<true, true>(P, persistent, numCUs, stream) : launchW<true, false>(P, persistent, numCUs, stream);
-    return count ? launchW<false, true>(P, persistent, numCUs, stream) : launchW<false, false>(P, persistent, numCUs, stream);
+    if (P.hasSpheres) {
+        if (any) return count ? launchW<true, true, true>(P, persistent, numCUs, stream) : launchW<true, false, true>(P, persistent, numCUs, stream);
+        return count ? launchW<false, true, true>(P, persistent, numCUs, stream) : launchW<false, false, true>(P, persistent, numCUs, stream);
+    }
+    if (any) return count ? launchW<true, true, false>(P, persistent, numCUs, stream) : launchW<true, false, false>(P, persistent, numCUs, stream);
+    return count ? launchW<false, true, false>(P, persistent, numCUs, stream) : launchW<false, false, false>(P, persistent, numCUs, stream);
 }
 
 } // namespace yart
