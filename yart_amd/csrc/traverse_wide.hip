@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
                 if (!exhausted) {
                     const uint32_t avail = chunkEnd - chunkNext;
                     const uint32_t rank = __popcll(idleMask & (laneBit - 1));
-                    if (!live && rank < avail) startRay(chunkNext + rank);
+                    if ((idleMask & laneBit) && rank < avail) startRay(chunkNext + rank);     // idle AND below the lane cap
                     chunkNext += ((uint32_t)nIdle < avail) ? (uint32_t)nIdle : avail;
                 }
             }
