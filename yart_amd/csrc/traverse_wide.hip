@@ -291,11 +291,11 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
 #pragma unroll
                     for (int c = 0; c < 4; ++c) tn[c] = h[c] ? tn[c] : inf;
                     YART_CSWAP(0, 1) YART_CSWAP(2, 3) YART_CSWAP(0, 2) YART_CSWAP(1, 3) YART_CSWAP(1, 2)
+                    cur = (tn[0] < inf) ? rf[0] : kNeedPop;
+                    __builtin_amdgcn_s_setprio(2);              // before the pushes: 0.6 % over raising it after them
                     if (tn[3] < inf) push(rf[3]);
                     if (tn[2] < inf) push(rf[2]);
                     if (tn[1] < inf) push(rf[1]);
-                    cur = (tn[0] < inf) ? rf[0] : kNeedPop;
-                    __builtin_amdgcn_s_setprio(2);
                 }
             }
         }
