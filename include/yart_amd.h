@@ -92,14 +92,21 @@ enum yart_flags {
     YART_SORT_RAYS      = 1u << 2,
     /* Distance-pruned traversal of the REFERENCE's binary tree (sphere-tree pass, then the
      * triangle tree, like include/scene.h:142-146) instead of the engine's own 4-wide
-     * triangle+sphere tree.  Same results as the default up to exact-t ties; slower. */
+     * triangle+sphere tree.  Same results as the default; slower. */
     YART_REFERENCE_TREE = 1u << 3,
-    /* Caller's promise that every ray of the batch has finite origin, finite non-zero
-     * 1/dir, minT == 0 and a maxT that is not NaN (what the reference's Ray constructor and
-     * renderer produce, include/vector.h:244-249): skips the fix-up launches that answer any
-     * other ray on the reference's tree. */
+    /* Skip the fix-up launches.  The default kernel leaves three kinds of ray to two small launches
+     * on the reference's tree that follow it: rays that are not "regular" (a non-finite origin, a
+     * zero or non-finite 1/dir component, minT != 0, NaN maxT -- the reference's Ray constructor
+     * and renderer produce none, include/vector.h:244-249), rays that start outside the scene's
+     * cover (yart_scene_cover), and rays that meet two triangles at bit-identical t in two
+     * different leaves of the reference's tree (which of them the reference keeps depends on its
+     * visiting order, src/bvhaccel.cpp:255-281).  With this flag such a ray comes back UNRESOLVED:
+     * YartHit.prim == YART_PRIM_UNRESOLVED, occlusion byte == YART_OCC_UNRESOLVED; the caller
+     * re-submits those rays with YART_REFERENCE_TREE, or knows that its batch holds none. */
     YART_RAYS_REGULAR   = 1u << 4
 };
+#define YART_PRIM_UNRESOLVED INT32_MIN
+#define YART_OCC_UNRESOLVED 2
 
 /* ---- accel lifetime -------------------------------------------------- */
 
@@ -226,6 +233,15 @@ int yart_build_host(const float* verts, size_t n_verts,
                     const int32_t* tris, size_t n_tris,
                     YartBvhNode* nodes_out, size_t* n_nodes,
                     YartTriAccel* triaccel_out);
+
+/* The scene's COVER (no HIP call; no counterpart in the reference): the box of ray origins for which the
+ * boxes of the engine's own tree are guaranteed to hold everything the reference's primitive tests can
+ * accept, rounding noise included (yart_amd/csrc/cover.h) -- the scene's bounds widened by 1/16 to 8 of its
+ * diagonals.  Rays that start outside it are answered on the reference's tree (fix-up launches).
+ * out[0..2] = lo, out[3..5] = hi, out[6] = D (longest distance from a covered origin to the scene),
+ * out[7] = M (largest |coordinate|), out[8] = 2^-20 D^2, out[9] = bits of a uint32: 0 for an empty scene
+ * (every origin covered). */
+int yart_scene_cover(const float* verts, size_t n_verts, const float* spheres, size_t n_spheres, float out[10]);
 
 /* Host-only build of the engine's 4-wide tree (no HIP call; layout as yart_accel_get_wide).
  * Call with NULL array outputs to query n_nodes / n_prims, then again with arrays of that

@@ -441,13 +441,56 @@ struct WideNodeRec {
 };
 static_assert(sizeof(WideNodeRec) == 64, "wide node is 64 bytes");
 
+// What the kernel needs beside the tree (yart_amd/csrc/traverse_wide.hip, cover.h): the reference's own nodes (the box of
+// a triangle's leaf there decides whether a hit in the triangle's error band counts, and whether two tied triangles
+// share a leaf), the cover of the scene (rays that start outside it are not answered by this walk) and the bounds of
+// the tree's grids (cull margin).
+struct WideAux {
+    const Node* refNodes = nullptr;
+    const uint32_t* leafOfSlot = nullptr;       // triangle slot -> index of its leaf in refNodes
+    float coverLo[3], coverHi[3];
+    bool coverValid = false;
+    float gridLo[3], gridHi[3], gridExt[3];
+};
+constexpr int32_t kUnresolved = INT32_MIN;      // yart_amd/csrc/traverse.h kUnresolvedPrim; any-hit: 2
+
+inline float bandOfClass(uint32_t cls)          // cover.h
+{
+    const uint32_t bits = (106u + 3u * cls) << 23;
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f;
+}
+
+inline bool regularRay(const Ray& r)            // yart_amd/csrc/traverse.h
+{
+    const float inf = std::numeric_limits<float>::infinity();
+    for (int a = 0; a < 3; ++a) {
+        const float i = 1.0f / r.d[a];
+        if (!(i != 0.0f && std::fabs(i) < inf && std::fabs(r.o[a]) < inf)) return false;
+    }
+    return r.tmin == 0.0f && r.tmax == r.tmax;
+}
+
+// returns 0 = miss / not occluded, 1 = hit / occluded, 2 = left to the walk of the reference's tree
 template <bool shadow>
-bool traverseWide(const WideNodeRec* nodes, const float* rowsA, const float* rowsBC, const Ray& r, Hit& out, Counters* c)
+int traverseWide(const WideNodeRec* nodes, const float* rowsA, const float* rowsBC, const WideAux& aux, const Ray& r, Hit& out, Counters* c)
 {
     const uint32_t kNone = 0xFFFFFFFFu, kLeaf = 0x80000000u, kSph = 0x40000000u;
     const float inf = std::numeric_limits<float>::infinity();
+    bool covered = true;
+    if (aux.coverValid)
+        for (int a = 0; a < 3; ++a) covered = covered && r.o[a] >= aux.coverLo[a] && r.o[a] <= aux.coverHi[a];
+    if (!regularRay(r) || !covered) { out.t = 0.0f; out.u = out.v = 0.0f; out.prim = kUnresolved; return 2; }
     const float ix = 1.0f / r.d[0], iy = 1.0f / r.d[1], iz = 1.0f / r.d[2];
     const float inv[3] = { ix, iy, iz };
+    float cm = 0.0f;
+    for (int a = 0; a < 3; ++a) {
+        const float f = std::fmax(std::fabs(r.o[a] - aux.gridLo[a]), std::fabs(aux.gridHi[a] - r.o[a])) + aux.gridExt[a];
+        cm = std::fmax(cm, std::fabs(inv[a]) * f);
+    }
+    cm *= 0x1p-21f;
+    if (!(cm < inf)) { out.t = 0.0f; out.u = out.v = 0.0f; out.prim = kUnresolved; return 2; }
     float tTri = r.tmax, hu = 0.0f, hv = 0.0f, F = inf;
     int32_t primTri = -1, minS = -1, maxL = -1;
     uint32_t stack[128];
@@ -457,7 +500,7 @@ bool traverseWide(const WideNodeRec* nodes, const float* rowsA, const float* row
         if (!(cur & kLeaf)) {
             const WideNodeRec& n = nodes[cur];
             if (c) c->nodes += 4;
-            const float bound = (shadow ? r.tmax : fmin2(tTri, F)) * kCullSlack;     // as traverse_wide.hip
+            const float bound = std::fma(shadow ? r.tmax : fmin2(tTri, F), kCullSlack, cm);     // as traverse_wide.hip
             float tn[4];
             uint32_t rf[4];
             int nHit = 0;
@@ -492,16 +535,29 @@ bool traverseWide(const WideNodeRec* nodes, const float* rowsA, const float* row
                     ta.n_u = A[0]; ta.n_v = A[1]; ta.n_d = A[2]; ta.k = (int32_t)(kw & 3u);
                     ta.b_u = BC[0]; ta.b_v = BC[1]; ta.b_d = BC[2];
                     ta.c_u = BC[4]; ta.c_v = BC[5]; ta.c_d = BC[6];
-                    const int32_t slot = (int32_t)(kw >> 2);
+                    const int32_t slot = (int32_t)((kw & 0x1FFFFFFCu) >> 2);
+                    const uint32_t cls = kw >> 29;
+                    // a hit within the triangle's error band of an edge counts only if the ray passes the box of the
+                    // triangle's leaf in the reference's tree (traverse_wide.hip, cover.h)
+                    auto counts = [&](float u, float v) {
+                        if (cls == 0 || !aux.refNodes) return true;
+                        if (!(fmin2(fmin2(v, u), 1.0f - (v + u)) < bandOfClass(cls))) return true;
+                        return slab(aux.refNodes[aux.leafOfSlot[slot]].b, r, r.tmax);
+                    };
                     float bound = shadow ? r.tmax : fmin2(tTri, F);
                     float u, v, t = bound;
                     if (wald(ta, r, t, u, v)) {
-                        if (shadow) return true;
+                        if (!counts(u, v)) continue;
+                        if (shadow) return 1;
                         tTri = t; hu = u; hv = v; primTri = slot;
-                    } else if (!shadow && primTri >= 0 && slot < primTri) {
-                        // exact-t tie: the lower leaf slot wins (see traverse_wide.hip)
+                    } else if (!shadow && primTri >= 0 && slot != primTri) {
+                        // an exact-t tie with the triangle held: inside one leaf of the reference's tree the lower slot
+                        // wins; across two of its leaves its visiting order decides (see traverse_wide.hip)
                         float t2 = std::nextafter(tTri, inf);
-                        if (wald(ta, r, t2, u, v) && t2 == tTri) { hu = u; hv = v; primTri = slot; }
+                        if (wald(ta, r, t2, u, v) && t2 == tTri && counts(u, v)) {
+                            if (aux.refNodes && aux.leafOfSlot[slot] != aux.leafOfSlot[primTri]) { out.t = 0.0f; out.u = out.v = 0.0f; out.prim = kUnresolved; return 2; }
+                            if (slot < primTri) { hu = u; hv = v; primTri = slot; }
+                        }
                     }
                 } else {
                     if (c) c->spheres++;
@@ -514,7 +570,7 @@ bool traverseWide(const WideNodeRec* nodes, const float* rowsA, const float* row
                     double t = b - det;
                     if (!(t > eps)) t = b + det;
                     if (!(t > eps && t < (double)r.tmax)) continue;
-                    if (shadow) return true;
+                    if (shadow) return 1;
                     const float f = (float)t;
                     if (f > fmin2(tTri, F)) continue;
                     uint32_t idxBits;
@@ -529,7 +585,7 @@ bool traverseWide(const WideNodeRec* nodes, const float* rowsA, const float* row
         if (sp == 0) break;
         cur = stack[--sp];
     }
-    if (shadow) return false;
+    if (shadow) return 0;
     const bool sph = (minS >= 0) && !(tTri < F);
     out.t = sph ? F : tTri;
     out.prim = sph ? -(std::max(minS, maxL) + 2) : primTri;
@@ -537,7 +593,7 @@ bool traverseWide(const WideNodeRec* nodes, const float* rowsA, const float* row
     out.v = sph ? 0.0f : hv;
     if (!(out.t < r.tmax)) out.prim = -1;
     if (out.prim == -1) { out.u = 0.0f; out.v = 0.0f; }
-    return out.prim != -1;
+    return out.prim != -1 ? 1 : 0;
 }
 
 template <class F>
@@ -659,14 +715,55 @@ void orc_intersect_shadow(void* h, const float* rays, size_t n, uint8_t* out, ui
 }
 
 // Stand-alone pieces for unit tests
-// The engine's wide tree walked on the CPU (see traverseWide).  Rays must be "regular" (finite
-// origin, finite non-zero 1/dir, minT == 0): the kernel defers any other ray to the reference tree.
+// The engine's wide tree walked on the CPU (see traverseWide).  Rays the kernel leaves to the fix-up launches on the
+// reference's tree (not regular, outside the cover, tied across two reference leaves) come back marked: prim =
+// INT32_MIN / occlusion byte 2.
+// refNodes / nRefNodes (optional): the reference's flattened nodes (yart_accel_get_nodes); cover (optional): the ten
+// words of yart_scene_cover.  Without them the walk runs without the near-edge check, the tie rule falls back to "lower
+// slot", and every origin counts as covered.
 // any != 0: occlusion query, out = uint8 per ray; else out = Hit per ray.
 // counts (optional): 4 x uint32 per ray = child records fetched, triangles tested, 0, spheres tested.
 void orc_wide_intersect(const void* nodes, const float* rowsA, const float* rowsBC, const float* rays, size_t n,
-                        void* out, uint32_t* counts, int any, int nthreads)
+                        void* out, uint32_t* counts, int any, int nthreads, const void* refNodes, size_t nRefNodes,
+                        const float* cover)
 {
     const WideNodeRec* nd = static_cast<const WideNodeRec*>(nodes);
+    WideAux aux;
+    std::vector<uint32_t> leafOfSlot;
+    if (refNodes && nRefNodes) {
+        aux.refNodes = static_cast<const Node*>(refNodes);
+        size_t nSlots = 0;
+        for (size_t i = 0; i < nRefNodes; ++i)
+            if (aux.refNodes[i].splitAxis == 3) nSlots = std::max(nSlots, (size_t)aux.refNodes[i].offset + aux.refNodes[i].numTriangles);
+        leafOfSlot.assign(nSlots, 0u);
+        for (size_t i = 0; i < nRefNodes; ++i)
+            if (aux.refNodes[i].splitAxis == 3)
+                for (uint32_t k = 0; k < aux.refNodes[i].numTriangles; ++k) leafOfSlot[aux.refNodes[i].offset + k] = (uint32_t)i;
+        aux.leafOfSlot = leafOfSlot.data();
+    }
+    if (cover) {
+        uint32_t valid;
+        std::memcpy(&valid, cover + 9, 4);
+        aux.coverValid = valid != 0;
+        for (int a = 0; a < 3; ++a) { aux.coverLo[a] = cover[a]; aux.coverHi[a] = cover[3 + a]; }
+    }
+    {
+        // bounds of the root's child boxes: every grid of the tree lies inside (the kernel takes the builder's figure;
+        // the margin only has to be wide enough, the result does not depend on it)
+        const float inf = std::numeric_limits<float>::infinity();
+        for (int a = 0; a < 3; ++a) { aux.gridLo[a] = inf; aux.gridHi[a] = -inf; }
+        for (int ch = 0; ch < 4; ++ch) {
+            if (nd[0].ref[ch] == 0xFFFFFFFFu) continue;
+            for (int a = 0; a < 3; ++a) {
+                aux.gridLo[a] = std::fmin(aux.gridLo[a], nd[0].origin[a] + nd[0].qlo[a][ch] * nd[0].scale[a]);
+                aux.gridHi[a] = std::fmax(aux.gridHi[a], nd[0].origin[a] + nd[0].qhi[a][ch] * nd[0].scale[a]);
+            }
+        }
+        for (int a = 0; a < 3; ++a) {
+            if (!(aux.gridLo[a] <= aux.gridHi[a])) aux.gridLo[a] = aux.gridHi[a] = 0.0f;
+            aux.gridExt[a] = 1.25f * (aux.gridHi[a] - aux.gridLo[a]);
+        }
+    }
     parallelFor(n, nthreads, [&](size_t b, size_t e) {
         for (size_t i = b; i < e; ++i) {
             Ray r;
@@ -674,8 +771,8 @@ void orc_wide_intersect(const void* nodes, const float* rowsA, const float* rows
             Hit hit;
             hit.t = r.tmax; hit.u = hit.v = 0.0f; hit.prim = -1;
             Counters c;
-            if (any) static_cast<uint8_t*>(out)[i] = traverseWide<true>(nd, rowsA, rowsBC, r, hit, counts ? &c : nullptr) ? 1 : 0;
-            else { traverseWide<false>(nd, rowsA, rowsBC, r, hit, counts ? &c : nullptr); static_cast<Hit*>(out)[i] = hit; }
+            if (any) static_cast<uint8_t*>(out)[i] = (uint8_t)traverseWide<true>(nd, rowsA, rowsBC, aux, r, hit, counts ? &c : nullptr);
+            else { traverseWide<false>(nd, rowsA, rowsBC, aux, r, hit, counts ? &c : nullptr); static_cast<Hit*>(out)[i] = hit; }
             if (counts) { counts[i * 4] = c.nodes; counts[i * 4 + 1] = c.tris; counts[i * 4 + 2] = 0; counts[i * 4 + 3] = c.spheres; }
         }
     });

@@ -121,12 +121,24 @@ class Oracle:
         return (occ, cnt) if counts else occ
 
 
-def wide_intersect(nodes, rows_a, rows_bc, rays, any_hit=False, counts=False, nthreads=8):
+UNRESOLVED_PRIM = -2**31        # a ray the wide kernel leaves to the fix-up launches (yart_amd/csrc/traverse.h)
+UNRESOLVED_OCC = 2
+
+
+def wide_intersect(nodes, rows_a, rows_bc, rays, any_hit=False, counts=False, nthreads=8, ref_nodes=None, cover=None):
     """The engine's 4-wide tree (dump of yart_accel_get_wide) walked on the CPU with the default
-    kernel's rule in its deterministic form (cpu_ref.cpp traverseWide)."""
+    kernel's rule in its deterministic form (cpu_ref.cpp traverseWide).  ref_nodes: the reference's
+    flattened nodes (near-edge check, tie rule); cover: the ten words of yart_scene_cover.  Rays the
+    kernel leaves to the fix-up launches come back with prim = UNRESOLVED_PRIM / occlusion UNRESOLVED_OCC."""
     build_oracle()
     L = ctypes.CDLL(ORACLE_SO)
-    L.orc_wide_intersect.argtypes = [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp, c_vp, ctypes.c_int, ctypes.c_int]
+    L.orc_wide_intersect.argtypes = [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp, c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_sz, c_vp]
+    if ref_nodes is not None:
+        ref_nodes = np.ascontiguousarray(ref_nodes)
+        assert ref_nodes.dtype.itemsize == 32
+    if cover is not None:
+        cover = np.ascontiguousarray(cover, np.float32)
+        assert cover.size == 10
     nodes = np.ascontiguousarray(nodes, np.uint32)
     rows_a = np.ascontiguousarray(rows_a, np.float32)
     rows_bc = np.ascontiguousarray(rows_bc, np.float32)
@@ -134,7 +146,7 @@ def wide_intersect(nodes, rows_a, rows_bc, rays, any_hit=False, counts=False, nt
     out = np.zeros(len(rays), np.uint8 if any_hit else HIT_DTYPE)
     cnt = np.zeros((len(rays), 4), np.uint32) if counts else None
     L.orc_wide_intersect(_p(nodes), _p(rows_a), _p(rows_bc), _p(rays), len(rays), _p(out), _p(cnt),
-                         1 if any_hit else 0, nthreads)
+                         1 if any_hit else 0, nthreads, _p(ref_nodes), 0 if ref_nodes is None else len(ref_nodes), _p(cover))
     return (out, cnt) if counts else out
 
 

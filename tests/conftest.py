@@ -34,3 +34,28 @@ def golden(request):
 
 def bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
+
+
+def wide_walk(verts, tris, spheres, rays, any_hit=False, built=None, counts=False):
+    """The default rule without a GPU, end to end: the oracle's walk of the engine's 4-wide tree (host-built unless
+    `built` = (nodes, rows_a, rows_bc) of another builder is given) with everything the kernel uses -- the reference's
+    nodes for the near-edge check and the tie rule, the scene's cover -- and, for the rays that walk leaves unresolved,
+    the pruned walk of the reference's own tree (oracle mode 1), which is what the fix-up launches run.
+    -> (results, number of rays that took the second path)"""
+    from oracle import oracle as orc
+    from yart_amd import api
+    if built is None:
+        built = api.build_wide_host(verts, tris, spheres)[:3]
+    ref_nodes = api.build_host(verts, tris)[0]
+    cover = api.scene_cover(verts, spheres)
+    rays = np.ascontiguousarray(rays, np.float32)
+    got = orc.wide_intersect(built[0], built[1], built[2], rays, any_hit=any_hit, ref_nodes=ref_nodes, cover=cover, counts=counts)
+    cnt = None
+    if counts:
+        got, cnt = got
+    left = (got == orc.UNRESOLVED_OCC) if any_hit else (got["prim"] == orc.UNRESOLVED_PRIM)
+    if left.any():
+        o = orc.Oracle(verts, tris, spheres)
+        sub = np.ascontiguousarray(rays[left])
+        got[left] = o.intersect_shadow(sub, mode=1) if any_hit else o.intersect(sub, mode=1)
+    return (got, int(left.sum()), cnt) if counts else (got, int(left.sum()))

@@ -36,16 +36,11 @@ def assert_exact(got, want_prim, want_t, want_u, want_v):
     assert np.array_equal(bits(got["v"][hit]), bits(want_v[hit]))
 
 
-def assert_within_bar(got, want_prim, want_t, exact_ties_ok=False):
-    """exact_ties_ok: a ray whose returned primitive differs but whose t is bit-identical to the
-    reference's (two primitives at exactly the same distance: a box corner, coplanar duplicates)
-    is not counted as a mismatch.  Which of the tied primitives the reference keeps depends on
-    the visiting order of ITS tree (first found wins); the 4-wide tree resolves ties to the lowest
-    leaf slot.  Only the constructed edge-case set (g3) needs this; it is stated in DESIGN.md."""
+def assert_within_bar(got, want_prim, want_t):
+    """The bar of BASELINE.json, no exceptions: exact-t ties (box corners, coplanar duplicates) resolve as in the
+    reference -- inside one of its leaves by slot order, across leaves by the fix-up launches on its own tree."""
     assert np.array_equal(got["prim"] != -1, want_prim != -1), "hit/miss differs"
     same_prim = got["prim"] == want_prim
-    if exact_ties_ok:
-        same_prim = same_prim | (bits(got["t"]) == bits(want_t))
     same = same_prim.mean()
     assert same >= MIN_SAME_PRIM, same
     m = want_prim != -1
@@ -76,10 +71,9 @@ def test_closest_reference_rule_is_bit_exact(golden, accel, launch):
 @pytest.mark.parametrize("tree", [0, api.YART_REFERENCE_TREE], ids=["wide", "reftree"])
 def test_closest_pruned_within_bar(golden, accel, launch, tree):
     got = api.hits_to_numpy(accel.intersect_closest(dev(golden["rays"]), launch | tree))
-    ties = tree == 0 and golden["name"] == "g3_edges.npz"
-    assert_within_bar(got, golden["prim"], golden["t"], exact_ties_ok=ties)
-    if ties:        # lowest-slot rule: coplanar duplicates resolve as in the reference; only corner ties remain
-        assert (got["prim"] != golden["prim"]).sum() <= 2
+    assert_within_bar(got, golden["prim"], golden["t"])
+    # the golden sets, the constructed edge cases of g3 included, are answered like the reference on EVERY ray
+    assert np.array_equal(got["prim"], golden["prim"]) and np.array_equal(bits(got["t"]), bits(golden["t"]))
 
 
 @pytest.mark.parametrize("launch", LAUNCHES)
@@ -184,6 +178,46 @@ def test_architectural_primary_rays_against_oracle():
     a.close()
 
 
+@pytest.mark.parametrize("build", ["host", "device"])
+@pytest.mark.parametrize("scene", ["slivers", "far_spheres", "near_spheres", "duplicates"])
+def test_ill_conditioned_scenes_agree_on_every_ray(scene, build, monkeypatch):
+    """Round 2's stated exceptions, now closed: slivers whose Wald test accepts points outside
+    the triangle, spheres whose fp32 determinant is noise, exact-t ties.  The default rule, closest hit and any-hit,
+    on both builders' trees, against the reference's rule on EVERY ray."""
+    from oracle import oracle as orc
+    monkeypatch.setenv("YART_BUILD_DEVICE", "1" if build == "device" else "0")
+    if scene == "slivers":
+        v, t, sph = scenes.random_soup(5000, 3000, s=0.01, seed=12)
+        rng = np.random.RandomState(2)
+        v = v.copy()
+        v[rng.rand(len(v)) < 0.001] *= 1000.0
+        rays = scenes.random_rays(40000, seed=3)
+    elif scene == "duplicates":
+        # every triangle three times (files with doubled faces): ties inside and across the reference's leaves
+        v, t, sph = scenes.random_soup(4000, 100, s=0.05, seed=5)
+        t = np.concatenate([t, t, t]).copy()
+        t[:, 4] = np.arange(len(t))
+        rays = scenes.random_rays(40000, seed=6)
+    else:
+        v, t, sph = scenes.random_soup(0, 60000, s=0.002, seed=4)
+        rays = scenes.random_rays(40000, seed=9)
+        if scene == "far_spheres":
+            rays[:, :3] = rays[:, :3] * 14 - 7
+    shadow = rays.copy()
+    shadow[:, 7] = 0.7
+    o = orc.Oracle(v, t, sph)
+    want = o.intersect(rays, mode=0, nthreads=16)
+    want_occ = o.intersect_shadow(shadow, mode=0, nthreads=16)
+    a = api.Accel(v, t, sph)
+    assert a.wide_built_on_device[0] == (build == "device")
+    for flags in (0, api.YART_SORT_RAYS, api.YART_REFERENCE_TREE, api.YART_REFERENCE_RULE):
+        got = api.hits_to_numpy(a.intersect_closest(dev(rays), flags))
+        assert np.array_equal(got["prim"], want["prim"]), (flags, int((got["prim"] != want["prim"]).sum()))
+        assert np.array_equal(bits(got["t"]), bits(want["t"]))
+        assert np.array_equal(a.intersect_any(dev(shadow), flags).cpu().numpy(), want_occ)
+    a.close()
+
+
 def regular_mask(rays):
     """regularRay() of yart_amd/csrc/traverse.h: the rays the wide-tree kernel takes itself."""
     with np.errstate(divide="ignore"):
@@ -194,28 +228,32 @@ def regular_mask(rays):
 
 def test_wide_tree_walk_on_cpu_agrees_with_kernel(golden, accel):
     """The 4-wide tree dumped from the accel and walked by the oracle's restatement of the default
-    kernel's rule gives the kernel's hits bit for bit; the kernel's fetch counters (speculative
-    descent may visit more) are never below the deterministic walk's and stay close to it."""
+    kernel's rule gives the kernel's own answers bit for bit -- including WHICH rays it leaves to the fix-up launches
+    (YART_RAYS_REGULAR returns them marked); the kernel's fetch counters (speculative descent may visit more) are never
+    below the deterministic walk's and stay close to it."""
     from oracle import oracle as orc
     nodes, rows_a, rows_bc = accel.wide()
-    assert nodes.shape[1] * 4 == 64 and len(rows_a) == len(golden["tris"]) + len(golden["spheres"])
-    m = regular_mask(golden["rays"])
-    rays = np.ascontiguousarray(golden["rays"][m])
-    want, want_cnt = orc.wide_intersect(nodes, rows_a, rows_bc, rays, counts=True)
+    assert nodes.shape[1] * 4 == 64 and len(rows_a) <= len(golden["tris"]) + len(golden["spheres"])
+    aux = dict(ref_nodes=accel.nodes(), cover=api.scene_cover(golden["verts"], golden["spheres"]))
+    rays = np.ascontiguousarray(golden["rays"])
+    want, want_cnt = orc.wide_intersect(nodes, rows_a, rows_bc, rays, counts=True, **aux)
     counts = torch.zeros((len(rays), 4), dtype=torch.int32, device="cuda")
     got = api.hits_to_numpy(accel.intersect_closest(dev(rays), api.YART_RAYS_REGULAR, counts=counts))
     assert np.array_equal(got["prim"], want["prim"])
+    left = want["prim"] == orc.UNRESOLVED_PRIM
+    assert left.sum() >= (~regular_mask(rays)).sum() and api.YART_PRIM_UNRESOLVED == orc.UNRESOLVED_PRIM
     assert np.array_equal(bits(got["t"]), bits(want["t"]))
     hit = want["prim"] >= 0
     assert np.array_equal(bits(got["u"][hit]), bits(want["u"][hit])) and np.array_equal(bits(got["v"][hit]), bits(want["v"][hit]))
-    cnt = counts.cpu().numpy().astype(np.int64)
-    assert (cnt >= want_cnt.astype(np.int64)).all()
+    cnt = counts.cpu().numpy().astype(np.int64)[~left]
+    want_cnt = want_cnt.astype(np.int64)[~left]
+    assert (cnt >= want_cnt).all()
     assert cnt[:, 0].sum() <= 1.25 * want_cnt[:, 0].sum() + 64
-    ms = regular_mask(golden["shadow_rays"])
-    sh = np.ascontiguousarray(golden["shadow_rays"][ms])
-    occ = orc.wide_intersect(nodes, rows_a, rows_bc, sh, any_hit=True)
+    sh = np.ascontiguousarray(golden["shadow_rays"])
+    occ = orc.wide_intersect(nodes, rows_a, rows_bc, sh, any_hit=True, **aux)
     assert np.array_equal(accel.intersect_any(dev(sh), api.YART_RAYS_REGULAR).cpu().numpy(), occ)
-    assert np.array_equal(occ, golden["occluded"][ms])
+    done = occ != orc.UNRESOLVED_OCC
+    assert np.array_equal(occ[done], golden["occluded"][done])
 
 
 def test_concurrent_submissions_on_distinct_streams():

@@ -11,7 +11,7 @@ import pytest
 
 import os
 
-from conftest import ROOT, bits
+from conftest import ROOT, bits, wide_walk
 from oracle import oracle as orc
 from yart_amd import api, scenes
 
@@ -80,7 +80,7 @@ def check_structure(g, nodes, rows_a, rows_bc, depth, max_leaf):
                         plo, phi = c3 - rad, c3 + rad
                     else:
                         kw = int(rows_a[i].view(np.uint32)[3])
-                        slot = kw >> 2
+                        slot = (kw & 0x1FFFFFFC) >> 2           # bits 29..31: class of the triangle's error band
                         seen_tri.append(slot)
                         t = ta[slot]
                         assert (kw & 3) == t["k"]
@@ -103,23 +103,16 @@ def check_structure(g, nodes, rows_a, rows_bc, depth, max_leaf):
 
 @pytest.mark.parametrize("max_leaf", [1, 4])
 def test_walk_matches_reference(golden, max_leaf):
+    """Every golden set at 100 %: exact-t ties across the reference's leaves included (g3: rays through box corners),
+    which the walk hands to the reference-tree walk like the kernel hands them to its fix-up launches."""
     g = golden
-    nodes, rows_a, rows_bc, _ = api.build_wide_host(g["verts"], g["tris"], g["spheres"], max_leaf)
-    m = regular_mask(g["rays"])
-    got = orc.wide_intersect(nodes, rows_a, rows_bc, np.ascontiguousarray(g["rays"][m]))
-    want_prim, want_t = g["prim"][m], g["t"][m]
-    assert np.array_equal(got["prim"] != -1, want_prim != -1)
-    same = got["prim"] == want_prim
-    if g["name"] == "g3_edges.npz":            # exact-t ties across the reference's leaves (parity bar)
-        same = same | (bits(got["t"]) == bits(want_t))
-        assert (got["prim"] != want_prim).sum() <= 2
-    assert same.mean() >= 0.9999
-    hit = want_prim != -1
-    rel = np.abs(got["t"][hit] - want_t[hit]) / np.abs(want_t[hit])
-    assert rel.size == 0 or rel.max() <= 1e-5
-    ms = regular_mask(g["shadow_rays"])
-    occ = orc.wide_intersect(nodes, rows_a, rows_bc, np.ascontiguousarray(g["shadow_rays"][ms]), any_hit=True)
-    assert np.array_equal(occ, g["occluded"][ms])
+    built = api.build_wide_host(g["verts"], g["tris"], g["spheres"], max_leaf)[:3]
+    got, left = wide_walk(g["verts"], g["tris"], g["spheres"], g["rays"], built=built)
+    assert left <= (~regular_mask(g["rays"])).sum() + 8
+    assert np.array_equal(got["prim"], g["prim"])
+    assert np.array_equal(bits(got["t"]), bits(g["t"]))
+    occ, _ = wide_walk(g["verts"], g["tris"], g["spheres"], g["shadow_rays"], any_hit=True, built=built)
+    assert np.array_equal(occ, g["occluded"])
 
 
 @pytest.mark.parametrize("n_tris,n_sph,s", [(0, 0, 0.1), (1, 0, 0.1), (0, 1, 0.1), (5, 3, 0.2), (3000, 300, 0.05), (20000, 0, 0.01),
@@ -127,56 +120,56 @@ def test_walk_matches_reference(golden, max_leaf):
 def test_seeded_scenes_against_reference_rule(n_tris, n_sph, s):
     v, t, sph = scenes.random_soup(n_tris, n_sph, s=s, seed=n_tris + 7 * n_sph + 1)
     rays = scenes.random_rays(20000, seed=3)
-    nodes, rows_a, rows_bc, _ = api.build_wide_host(v, t, sph)
-    got = orc.wide_intersect(nodes, rows_a, rows_bc, rays)
+    got, left = wide_walk(v, t, sph, rays)
     want = orc.Oracle(v, t, sph).intersect(rays, mode=0)
+    if n_tris + n_sph >= 3000:                           # the soup fills the unit cube the rays start in, and nothing ties:
+        assert left == 0                                 # the wide tree answers every ray
     assert np.array_equal(got["prim"], want["prim"])
     assert np.array_equal(bits(got["t"]), bits(want["t"]))
 
 
-def test_ill_conditioned_slivers_stay_within_the_stated_exception():
-    """DESIGN.md section 1, third exception: slivers a thousand times the size of the rest make Wald's test accept
-    points outside the triangle, and which of those a traversal meets depends on its boxes.  The default walk may then
-    differ from the reference -- by a bounded share of the rays; the pruned walk over the reference's own boxes
-    (oracle mode 1, what YART_REFERENCE_TREE runs) still returns the reference's answer on every ray."""
-    worst = 0.0
-    for seed in (0, 2):
+def test_ill_conditioned_slivers_agree_with_the_reference():
+    """Slivers a thousand times the size of the rest make Wald's test accept points outside the triangle -- a band wider
+    than the sliver -- and which of those a traversal meets depends on its boxes: the reference's leaf box for that
+    triangle.  Round 2 documented 10-45 differing rays of 20 000 here.  The default rule now agrees on every ray: the
+    triangle's own box holds its whole error band (cover.h: triBand) and a hit inside the band counts only if the ray
+    passes the reference's leaf box (the kernel's near-edge check), closest hit and any-hit."""
+    for seed in (0, 2, 5):
         v, t, sph = scenes.random_soup(5000, 3000, s=0.01, seed=seed + 10)
         rng = np.random.RandomState(seed)
         v = v.copy()
         v[rng.rand(len(v)) < 0.001] *= 1000.0
         rays = scenes.random_rays(20000, seed=seed + 1)
+        shadow = scenes.random_rays(20000, seed=seed + 3, tmax=0.7)
         o = orc.Oracle(v, t, sph)
         want = o.intersect(rays, mode=0)
-        pruned = o.intersect(rays, mode=1)
-        assert np.array_equal(pruned["prim"], want["prim"]) and np.array_equal(bits(pruned["t"]), bits(want["t"]))
-        nodes, rows_a, rows_bc, _ = api.build_wide_host(v, t, sph)
-        got = orc.wide_intersect(nodes, rows_a, rows_bc, rays)
-        worst = max(worst, float((got["prim"] != want["prim"]).mean()))
-    assert 0.0 < worst <= 0.005          # present (else the exception can be struck from DESIGN.md), and small
+        got, _ = wide_walk(v, t, sph, rays)
+        assert np.array_equal(got["prim"], want["prim"]) and np.array_equal(bits(got["t"]), bits(want["t"]))
+        occ, _ = wide_walk(v, t, sph, shadow, any_hit=True)
+        assert np.array_equal(occ, o.intersect_shadow(shadow, mode=0))
 
 
-def test_tiny_far_spheres_stay_within_the_stated_exception():
-    """Same exception, the sphere side: the reference's test forms b*b - |op|^2 + r^2 from fp32 b and |op|^2, so for a
-    sphere of radius 1e-3 seen from 10 units away the rounding of |op|^2 (about 1e-5) exceeds r^2 (1e-6) and the test
-    accepts rays that pass several radii beside the sphere.  The reference loops over all spheres and meets every such
-    false positive; a tree meets those whose boxes the ray enters."""
+def test_tiny_far_spheres_agree_with_the_reference():
+    """The sphere side: the reference's test forms b*b - |op|^2 + r^2 from fp32 b and |op|^2, so for a sphere of radius
+    1e-3 seen from 10 units away the rounding of |op|^2 (about 1e-5) exceeds r^2 (1e-6) and the test accepts rays that
+    pass several radii beside the sphere.  The reference loops over all spheres and meets every such false positive;
+    round 2 differed on 3 of 20 000 rays.  Now: a sphere's box has radius sqrt(r^2 + 2^-20 D^2) for the rays of the
+    scene's cover, and rays from outside it (all of these: origins up to 7 units from a unit scene) are left to the
+    reference-tree path."""
     v, t, sph = scenes.random_soup(0, 60000, s=0.002, seed=4)
     rays = scenes.random_rays(20000, seed=9)
     rays[:, :3] = rays[:, :3] * 14 - 7
     o = orc.Oracle(v, t, sph)
     want = o.intersect(rays, mode=0, nthreads=8)
-    nodes, rows_a, rows_bc, _ = api.build_wide_host(v, t, sph)
-    got = orc.wide_intersect(nodes, rows_a, rows_bc, rays)
-    differ = np.nonzero(got["prim"] != want["prim"])[0]
-    assert len(differ) <= 0.002 * len(rays)
-    # where they differ, the reference's hit point lies outside the sphere it reports: a false positive
-    for i in differ:
-        if want["prim"][i] >= -1:
-            continue
-        c = sph[-(int(want["prim"][i]) + 2)].astype(np.float64)
-        p = rays[i, :3].astype(np.float64) + float(want["t"][i]) * rays[i, 4:7].astype(np.float64)
-        assert np.linalg.norm(p - c[:3]) > 1.2 * c[3]
+    got, left = wide_walk(v, t, sph, rays)
+    assert left > 15000
+    assert np.array_equal(got["prim"], want["prim"]) and np.array_equal(bits(got["t"]), bits(want["t"]))
+    # the same spheres seen from inside the cover: the padded boxes alone must do
+    near = scenes.random_rays(20000, seed=10)
+    want = o.intersect(near, mode=0, nthreads=8)
+    got, left = wide_walk(v, t, sph, near)
+    assert left == 0
+    assert np.array_equal(got["prim"], want["prim"]) and np.array_equal(bits(got["t"]), bits(want["t"]))
 
 
 def test_degenerate_inputs_build():
@@ -189,11 +182,11 @@ def test_degenerate_inputs_build():
     assert depth >= 1 and len(nodes) >= 1
     rays = np.array([[0.25, 0.25, -5, 0, 0.01, 0.02, 1.0, np.inf]], np.float32)
     rays[:, 4:7] /= np.linalg.norm(rays[:, 4:7])
-    got = orc.wide_intersect(nodes, rows_a, rows_bc, rays)
+    got, _ = wide_walk(v, t, sph, rays)
     want = orc.Oracle(v, t, sph).intersect(rays, mode=0)
-    # 21 identical triangles tie exactly; more than fit one of the reference's leaves, so which one it
-    # keeps depends on its visiting order -- the t bits are what must agree
-    assert got["prim"][0] >= 0 and want["prim"][0] >= 0 and bits(got["t"])[0] == bits(want["t"])[0]
+    # 21 identical triangles tie exactly; more than fit one of the reference's leaves, so which one it keeps depends
+    # on its visiting order: the walk hands the ray to the reference-tree walk
+    assert got["prim"][0] >= 0 and got["prim"][0] == want["prim"][0] and bits(got["t"])[0] == bits(want["t"])[0]
 
 
 def test_builders_do_not_depend_on_thread_count():
@@ -232,10 +225,10 @@ def test_scene_with_non_finite_vertices():
     rays[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
     rays[:, 7] = np.inf
     want = ref.intersect(rays)
-    got = orc.wide_intersect(n, a, b, rays)
+    got, _ = wide_walk(o["verts"], o["tris"], o["spheres"], rays, built=(n, a, b))
     assert (want["prim"] != -1).sum() > 1000
     assert np.array_equal(bits(got["t"]), bits(want["t"]))
-    assert (got["prim"] == want["prim"]).mean() >= 0.9999
+    assert np.array_equal(got["prim"], want["prim"])
 
 
 def test_packed_form_round_trip():

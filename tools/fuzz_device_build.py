@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""One-off fuzz of the device builders (GPU box): random scenes of many sizes and shapes, device-built accel against
-host-built accel -- the reference's arrays byte for byte, closest-hit / any-hit answers of all three rules equal.
+"""Fuzz of the builders and of every traversal rule (GPU box): random scenes of many sizes and shapes, device-built and
+host-built accel -- the reference's arrays byte for byte between the two, closest-hit / any-hit answers of all rules equal
+to the reference's rule restated on the CPU, on every ray.
     python tools/fuzz_device_build.py [rounds] [seed]"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from yart_amd import api, scenes
+from oracle import oracle as orc          # the checker: this script is a test tool
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -16,7 +18,7 @@ for it in range(rounds):
     n_sph = int(rng.choice([0, 1, 50, 1023, 1024, 3000, 60000]))
     kind = rng.randint(4)
     if kind == 0 or n_tris < 1000:
-        kind = 0        # rays stay in the unit cube: spheres of radius 1e-3 seen from 10 units away are ill conditioned
+        kind = 0
         v, t, s = scenes.random_soup(n_tris, n_sph, s=float(rng.choice([0.002, 0.02, 0.2])), seed=int(rng.randint(1 << 30)))
     elif kind == 1:
         v, t, _ = scenes.architectural(max(n_tris, 2000), seed=int(rng.randint(1 << 30)))
@@ -41,6 +43,9 @@ for it in range(rounds):
         continue
     if only >= 0:
         np.savez("gpurun_out/fuzz_round_%d.npz" % it, verts=v, tris=t, spheres=s, rays=rays, shadow=shadow)
+    o = orc.Oracle(v, t, s)
+    want = o.intersect(rays, mode=0, nthreads=16)
+    want_occ = o.intersect_shadow(shadow, mode=0, nthreads=16)
     res = {}
     failed = {}
     for mode in ("1", "0"):
@@ -64,30 +69,18 @@ for it in range(rounds):
     why = []
     if res["1"][0] != res["0"][0]: why.append("nodes")
     if res["1"][1] != res["0"][1]: why.append("triaccel")
-    for k, (x, y) in enumerate(zip(res["1"][2], res["0"][2])):
-        if k >= 2 and not np.array_equal(x.view(np.int32), y.view(np.int32)):
-            d = np.nonzero((x.view(np.int32) != y.view(np.int32)).any(1))[0]
-            why.append("closest[%d]: %d rays differ, first %d: %s vs %s ray %s" % (k, len(d), d[0], x[d[0]].tolist() + [int(x[d[0], 3:].view(np.int32)[0])], y[d[0]].tolist() + [int(y[d[0], 3:].view(np.int32)[0])], rays[d[0]].tolist()))
-    for k, (x, y) in enumerate(zip(res["1"][3], res["0"][3])):
-        if not np.array_equal(x, y): why.append("any[%d]: %d differ" % (k, int((x != y).sum())))
-    ok = res["1"][0] == res["0"][0] and res["1"][1] == res["0"][1]
-    # reference-tree rules: same tree, same kernels -> identical; default rule: another wide tree -> same prim & t (ties aside)
-    ok = ok and all(np.array_equal(x.view(np.int32), y.view(np.int32)) for x, y in zip(res["1"][2][2:], res["0"][2][2:]))
-    # any-hit: the reference rule must agree exactly; the default rule too, the ill-conditioned slivers of kind 3 aside
-    ok = ok and np.array_equal(res["1"][3][1], res["0"][3][1])
-    ok = ok and (res["1"][3][0] != res["0"][3][0]).mean() <= (0.01 if kind == 3 else 0.0)
-    # The default rule against the pruned rule on the reference's tree: the parity bar.  kind 3 holds sliver triangles a
-    # thousand times the size of the rest, whose Wald test accepts points within float error OUTSIDE the triangle; which
-    # of those a traversal meets depends on its boxes (third exception), so the bar is relaxed there.
-    bar = 0.99 if kind == 3 else 0.9999
-    ref_tree = res["0"][2][2]
+    # Every rule on both builders' trees against the reference's rule restated on the CPU (oracle mode 0), on every ray:
+    # primitive and t bits, occlusion bytes.  No relaxed bars: slivers (kind 3), tiny far spheres (kinds 1, 2 see the
+    # spheres from up to 7 units outside the scene) and exact ties (kind 2) are answered like the reference.
+    names = ("default", "sorted", "reference tree", "reference rule")
     for mode in ("1", "0"):
-        for x in res[mode][2][:2]:
-            # another primitive at the SAME t bits is an exact tie (first exception), not a miss
-            same = (x[:, 3].view(np.int32) == ref_tree[:, 3].view(np.int32)) | (x[:, 0].view(np.int32) == ref_tree[:, 0].view(np.int32))
-            if same.mean() < bar:
-                ok = False
-                why.append("default rule, build %s: the reference tree's primitive (or an exact tie) for %.5f of the rays" % (mode, same.mean()))
+        for k, x in enumerate(res[mode][2]):
+            d = np.nonzero((x[:, 3].view(np.int32) != want["prim"]) | (x[:, 0].view(np.uint32) != want["t"].view(np.uint32)))[0]
+            if len(d):
+                why.append("closest, %s, build %s: %d rays differ, first %d: %s vs %s" % (names[k], mode, len(d), d[0], (x[d[0], 0], int(x[d[0], 3:].view(np.int32)[0])), (want["t"][d[0]], want["prim"][d[0]])))
+        for k, x in enumerate(res[mode][3]):
+            if not np.array_equal(x, want_occ): why.append("any, %s, build %s: %d differ" % (("default", "reference rule")[k], mode, int((x != want_occ).sum())))
+    ok = not why
     print("round %2d kind %d tris %7d spheres %6d device-built wide=%s ref=%s median ranges %d nan records %d: %s"
           % (it, kind, len(t), len(s), res["1"][4], res["1"][5][0], res["1"][5][2], res["1"][5][3], "ok" if ok else "MISMATCH " + "; ".join(why)), flush=True)
     bad += 0 if ok else 1

@@ -18,6 +18,8 @@ YART_STATIC_LAUNCH = 1 << 1
 YART_SORT_RAYS = 1 << 2
 YART_REFERENCE_TREE = 1 << 3
 YART_RAYS_REGULAR = 1 << 4
+YART_PRIM_UNRESOLVED = -2**31       # a ray left to the fix-up launches, seen only with YART_RAYS_REGULAR
+YART_OCC_UNRESOLVED = 2
 YART_NOALLOC_MAX_RAYS = 2097152
 
 NODE_DTYPE = np.dtype([("bounds", np.float32, 6), ("offset", np.uint32),
@@ -37,7 +39,7 @@ EXPORTS = [
     "yart_accel_get_nodes", "yart_accel_get_triaccel", "yart_accel_depth",
     "yart_accel_device_bytes", "yart_build_host", "yart_status_string", "yart_last_error",
     "yart_accel_profile_enable", "yart_accel_profile_read",
-    "yart_build_wide_host", "yart_accel_num_wide_nodes", "yart_accel_num_wide_prims", "yart_accel_wide_depth", "yart_accel_get_wide", "yart_accel_wide_built_on_device", "yart_accel_ref_built_on_device",
+    "yart_scene_cover", "yart_build_wide_host", "yart_accel_num_wide_nodes", "yart_accel_num_wide_prims", "yart_accel_wide_depth", "yart_accel_get_wide", "yart_accel_wide_built_on_device", "yart_accel_ref_built_on_device",
     "yart_obj_load", "yart_obj_free", "yart_obj_num_meshes", "yart_obj_num_vertices", "yart_obj_num_triangles",
     "yart_obj_num_materials", "yart_obj_num_spheres", "yart_obj_get", "yart_obj_mesh_name", "yart_obj_material_name",
     "yart_film_tonemap", "yart_film_write_bmp",
@@ -199,6 +201,18 @@ def build_host(verts, tris):
     ta = np.zeros(len(tris), TRIACCEL_DTYPE)
     _check(L.yart_build_host(_p(verts), len(verts), _p(tris), len(tris), _p(nodes), ctypes.byref(n), _p(ta)))
     return nodes, ta
+
+
+def scene_cover(verts, spheres=None):
+    """-> float32[10]: the scene's cover (include/yart_amd.h: yart_scene_cover)."""
+    L = lib()
+    verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
+    spheres = np.zeros((0, 4), np.float32) if spheres is None else np.ascontiguousarray(spheres, np.float32).reshape(-1, 4)
+    out = np.zeros(10, np.float32)
+    L.yart_scene_cover.argtypes = [_vp, _sz, _vp, _sz, _vp]
+    L.yart_scene_cover.restype = ctypes.c_int
+    _check(L.yart_scene_cover(_p(verts), len(verts), _p(spheres), len(spheres), _p(out)))
+    return out
 
 
 def build_wide_host(verts, tris, spheres=None, max_leaf=1):

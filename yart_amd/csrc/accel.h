@@ -12,6 +12,7 @@
 
 #include "../../include/yart_amd.h"
 #include "bvh_build.h"
+#include "cover.h"
 
 struct YartAccel {
     int device = 0;
@@ -30,12 +31,15 @@ struct YartAccel {
     std::mutex hostCopyMutex;
     int sphDepth = 0;
     float sceneLo[3], sceneHi[3];     // bounds of everything, for the sort key grid
+    yart::Cover cover;                // the rays the primitives' boxes are padded for (cover.h)
+    float gridLo[3] = { 0, 0, 0 }, gridHi[3] = { 0, 0, 0 };   // bounds of the wide tree's (padded) primitive boxes
     // device memory
     void* dTriPairs = nullptr;
     void* dTriAccel = nullptr;
     void* dSphPairs = nullptr;
     void* dSphRecs = nullptr;
     void* dSphIndex = nullptr;
+    void* dLeafOfSlot = nullptr;      // per triangle slot: where its leaf's record sits in dTriPairs (traverse.h: launchLeafOfSlot)
     void* dWideUnits = nullptr;       // the engine's own 4-wide triangle+sphere tree, packed (wide_build.h: PackedWide)
     size_t wideUnits = 0;
     void* dSurfRows = nullptr;        // hit post-processing (yart_accel_set_surface_data)

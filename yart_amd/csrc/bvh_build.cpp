@@ -359,10 +359,10 @@ int buildTriangleBvh(const float* verts, size_t nVerts, const int32_t* tris, siz
 
 // Sphere BVH: the reference has none (linear loop, include/scene.h:142-144), so the
 // tree shape is the engine's own: same midpoint/median splitter as the triangle
-// tree, leaves of at most 4 spheres, leaf slots in left-to-right order.  Boxes are
-// the sphere extents widened by a relative margin so that the fp32 slab test never
-// rejects a ray the fp64 sphere test (include/sphere.h:63-97) would accept.
-int buildSphereBvh(const float* spheres, size_t nSpheres, SphereBvh& out, std::string& err)
+// tree, leaves of at most 4 spheres, leaf slots in left-to-right order.  A sphere's box
+// holds everything the fp64 sphere test (include/sphere.h:63-97) can accept from a
+// covered ray, its rounding noise included (cover.h: sphereBox).
+int buildSphereBvh(const float* spheres, size_t nSpheres, const Cover& cover, SphereBvh& out, std::string& err)
 {
     out = SphereBvh{};
     if (nSpheres == 0) return YART_OK;
@@ -373,14 +373,9 @@ int buildSphereBvh(const float* spheres, size_t nSpheres, SphereBvh& out, std::s
     std::vector<Prim> prims(nSpheres);
     for (size_t i = 0; i < nSpheres; ++i) {
         const float* s = spheres + i * 4;
-        const float r = std::fabs(s[3]);
         Prim& p = prims[i];
-        for (int a = 0; a < 3; ++a) {
-            const float margin = 1e-5f * (std::fabs(s[a]) + r) + 1e-30f;
-            p.box.lo[a] = s[a] - r - margin;
-            p.box.hi[a] = s[a] + r + margin;
-            p.centre[a] = s[a];
-        }
+        sphereBox(s, std::sqrt(sphereReff2(s, cover)), p.box.lo, p.box.hi);
+        for (int a = 0; a < 3; ++a) p.centre[a] = s[a];
         p.id = static_cast<uint32_t>(i);
     }
     FlatTree t;

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/yart_amd.h"
+#include "cover.h"
 
 namespace yart {
 
@@ -69,7 +70,7 @@ struct SphereBvh {
 // Returns YART_OK or an error status; `err` receives a message on failure.
 int buildTriangleBvh(const float* verts, size_t nVerts, const int32_t* tris, size_t nTris,
                      TriangleBvh& out, std::string& err);
-int buildSphereBvh(const float* spheres, size_t nSpheres, SphereBvh& out, std::string& err);
+int buildSphereBvh(const float* spheres, size_t nSpheres, const Cover& cover, SphereBvh& out, std::string& err);
 
 // One TriAccel record (include/triaccel.h:54-108) with the host's arithmetic; the device builder
 // (ref_build_dev.hip) uses it for the degenerate triangles whose records hold NaNs.

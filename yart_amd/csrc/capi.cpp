@@ -197,6 +197,9 @@ int runIntersect(YartAccel* a, const Launch& L, const CallScratch* given)
     P.counts = L.counts;
     P.refillMin = a->refillMin;
     P.nodeMin = a->nodeMin;
+    P.cover = a->cover;
+    std::memcpy(P.sceneLo, a->sceneLo, 12);
+    std::memcpy(P.sceneHi, a->sceneHi, 12);
     hipError_t e = hipSuccess;
     const bool useWide = a->hasWide && !(L.flags & (YART_REFERENCE_RULE | YART_REFERENCE_TREE));
     P.deferFlag = nullptr;
@@ -213,12 +216,19 @@ int runIntersect(YartAccel* a, const Launch& L, const CallScratch* given)
         W.deferFlag = W.workCounter + 1;
         W.deferList = slot0 + 256;                  // behind the four counter slots (accel.h: kCounterBlockBytes)
         W.deferCap = yart::kDeferCap;
+        W.refPairs = static_cast<const float4*>(a->dTriPairs);
+        W.leafOfSlot = static_cast<const uint32_t*>(a->dLeafOfSlot);
+        W.cover = a->cover;
+        std::memcpy(W.gridLo, a->gridLo, 12);
+        std::memcpy(W.gridHi, a->gridHi, 12);
+        for (int c = 0; c < 3; ++c) W.gridExt[c] = 1.25f * (a->gridHi[c] - a->gridLo[c]);
         W.refillMin = a->wideRefillMin; W.nodeMin = a->wideNodeMin; W.sphereMin = a->wideSphereMin; W.chunk = a->wideChunk; W.maxBlocksPerCU = a->wideBlocksPerCU; W.laneCap = a->wideLaneCap; W.hasSpheres = a->numSpheres > 0 ? 1u : 0u;
         {
             ScopedSpan span(a, 2, L.stream);
             e = yart::launchTraceWide(W, L.any, L.count, persistent, a->numCUs, L.stream);
         }
-        // rays the wide kernel does not take (!regularRay) are answered on the reference tree
+        // rays the wide kernel does not take (irregular, outside the cover, tied across reference leaves) are answered on
+        // the reference tree
         P.deferFlag = W.deferFlag;
         P.deferList = W.deferList;
         P.deferCap = W.deferCap;
@@ -315,6 +325,12 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
     const bool deviceByDefault = n_tris + n_spheres >= (size_t(1) << 18);
     const bool wantDeviceBuild = wantWide && (devBuild ? devBuild[0] == '1' : deviceByDefault) && n_tris + n_spheres >= 2;
     const auto tBuild0 = std::chrono::steady_clock::now();
+    if ((n_tris && (!verts || !tris)) || n_tris >= yart::kMaxLeafSlot || (n_spheres && !spheres) || n_spheres >= yart::kMaxLeafSlot) {
+        delete a;
+        return fail(YART_ERR_INVALID_ARGUMENT, "yart_accel_create: null scene array or too many primitives");
+    }
+    a->cover = yart::sceneCover(verts, n_verts, spheres, n_spheres);
+    const yart::Cover cover = a->cover;
     yart::DeviceWideBuilder devBuilder;
     std::thread devThread;
     int devStatus = YART_ERR_HIP;
@@ -322,7 +338,7 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
     if (wantDeviceBuild) {
         devThread = std::thread([&]() {
             if (hipSetDevice(device) != hipSuccess) { devErr = "hipSetDevice failed"; return; }
-            devStatus = devBuilder.topology(verts, n_verts, tris, n_tris, spheres, n_spheres, devErr);
+            devStatus = devBuilder.topology(verts, n_verts, tris, n_tris, spheres, n_spheres, cover, devErr);
         });
     }
     // ... and so is the reference's own tree (ref_build_dev.hip), bit for bit, once the scene is on the device;
@@ -344,7 +360,7 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
         // the sphere tree of the reference-tree path: on the host while the device sorts, or -- from 1024 spheres --
         // by the same device builder afterwards
         const bool wantDeviceSph = n_spheres >= 1024;
-        if (!wantDeviceSph) st = yart::buildSphereBvh(spheres, n_spheres, sph, err);
+        if (!wantDeviceSph) st = yart::buildSphereBvh(spheres, n_spheres, cover, sph, err);
         devThread.join();
         if (st == YART_OK && devStatus == YART_OK) {
             bool useHost = false;
@@ -352,15 +368,15 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
             refOnDevice = st == YART_OK && !useHost;
             if (st == YART_OK && wantDeviceSph) {
                 useHost = false;
-                st = yart::buildSphereTreeDevice(devBuilder.deviceSpheres(), n_spheres, devSph, &useHost, err);
+                st = yart::buildSphereTreeDevice(devBuilder.deviceSpheres(), n_spheres, cover, devSph, &useHost, err);
                 sphOnDevice = st == YART_OK && !useHost;
             }
         }
         if (st == YART_OK && !refOnDevice) st = yart::buildTriangleBvh(verts, n_verts, tris, n_tris, a->tri, err);
-        if (st == YART_OK && wantDeviceSph && !sphOnDevice) st = yart::buildSphereBvh(spheres, n_spheres, sph, err);
+        if (st == YART_OK && wantDeviceSph && !sphOnDevice) st = yart::buildSphereBvh(spheres, n_spheres, cover, sph, err);
     } else {
         st = yart::buildTriangleBvh(verts, n_verts, tris, n_tris, a->tri, err);
-        if (st == YART_OK) st = yart::buildSphereBvh(spheres, n_spheres, sph, err);
+        if (st == YART_OK) st = yart::buildSphereBvh(spheres, n_spheres, cover, sph, err);
         if (devThread.joinable()) devThread.join();
     }
     const double msRefTree = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tBuild0).count();
@@ -369,7 +385,7 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
     if (st == YART_OK && wantWide && !useDeviceBuild) {
         const int maxLeaf = 1;      // measured best on MI355X (tools/exp_wide.py): the box of a single primitive is a
                                     // cheaper rejection than its plane row, and rows of different leaves are not tested
-        st = yart::buildWideBvh(verts, n_verts, tris, n_tris, a->tri, spheres, n_spheres, maxLeaf, wide, err);
+        st = yart::buildWideBvh(verts, n_verts, tris, n_tris, a->tri, spheres, n_spheres, maxLeaf, cover, wide, err);
     }
     if (st != YART_OK) { devRef.release(); devSph.release(); delete a; return fail(st, err); }
     a->numTriPairs = refOnDevice ? devRef.numPairs : a->tri.pairs.size();
@@ -442,6 +458,8 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
         if (st != YART_OK) st = fail(st, err);
         else {
             a->dWideUnits = dw.units; a->wideUnits = dw.numUnits;
+            std::memcpy(a->gridLo, dw.rootLo, 12);
+            std::memcpy(a->gridHi, dw.rootHi, 12);
             a->wideNodes = dw.numNodes; a->widePrims = dw.numPrims; a->wideDepth = dw.depth;
             a->deviceBytes += dw.numUnits * 16;
             a->hasWide = true;
@@ -456,10 +474,20 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
         if (!yart::packWide(wide, packed)) { err = "wide BVH does not fit the packed format"; st = fail(YART_ERR_INVALID_ARGUMENT, err); }
         else st = upload(&a->dWideUnits, packed.words.data(), packed.numUnits * 16, a->deviceBytes);
         a->wideUnits = packed.numUnits;
+        std::memcpy(a->gridLo, wide.rootLo, 12);
+        std::memcpy(a->gridHi, wide.rootHi, 12);
         a->hasWide = (st == YART_OK);
         a->wideNodes = wide.nodes.size();
         a->widePrims = wide.rowsA.size() / 4;
         a->wideDepth = wide.depth;
+    }
+    if (st == YART_OK && a->hasWide && n_tris) {
+        // per triangle slot, where its leaf's box sits in the reference's pair array (traverse_wide.hip: near-edge hits, ties)
+        hipError_t e = hipMalloc(&a->dLeafOfSlot, n_tris * 4);
+        if (e == hipSuccess) e = yart::launchLeafOfSlot(a->dTriPairs, a->numTriPairs, static_cast<uint32_t*>(a->dLeafOfSlot), nullptr);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess) st = failHip(e, "leaf table of the reference tree");
+        else a->deviceBytes += n_tris * 4;
     }
     // this device's copy of the static scratch of yart_intersect_closest_noalloc_dev (looked up once per
     // device, with that device current)
@@ -490,6 +518,7 @@ void yart_accel_destroy(YartAccel* a)
             delete kv.second;
         }
         (void)hipFree(a->dWideUnits);
+        (void)hipFree(a->dLeafOfSlot);
         (void)hipFree(a->dSurfRows);
         (void)hipFree(a->dSurfSpheres);
         for (auto& c : a->stagingFree) {
@@ -555,17 +584,24 @@ static int pooledHostCall(YartAccel* accel, const YartRay* rays, size_t n, YartH
         std::memcpy(c.host, rays, n * sizeof(YartRay));
         char* dOut = static_cast<char*>(c.dev) + kStagingRays * sizeof(YartRay);
         const char* hOut = static_cast<char*>(c.host) + kStagingRays * sizeof(YartRay);
-        // a handful of rays cannot fill persistent workgroups: plain grid.  The rays are in host
-        // memory here, so whether any of them needs the fix-up launches is known up front.
-        bool regular = true;
-        for (size_t i = 0; i < n && regular; ++i)
-            regular = yart::regularRay(rays[i].ox, rays[i].oy, rays[i].oz, rays[i].tmin, rays[i].dx, rays[i].dy, rays[i].dz, rays[i].tmax);
-        const unsigned f = flags | YART_STATIC_LAUNCH | (regular ? YART_RAYS_REGULAR : YART_REFERENCE_TREE);
-        st = hits ? yart_intersect_closest_dev(accel, static_cast<YartRay*>(c.dev), n, reinterpret_cast<YartHit*>(dOut), f, c.stream)
-                  : yart_intersect_any_dev(accel, static_cast<YartRay*>(c.dev), n, reinterpret_cast<uint8_t*>(dOut), f, c.stream);
-        if (st == YART_OK) {
-            const hipError_t e = hipStreamSynchronize(c.stream);
-            if (e != hipSuccess) st = failHip(e, "hipStreamSynchronize");
+        // a handful of rays cannot fill persistent workgroups: plain grid.  The default kernel alone first (no fix-up
+        // launches: one-ray calls are launch bound); the block is host memory, so whether it left a ray unresolved
+        // (irregular, outside the cover, tied across reference leaves) shows in the results, and only then is the
+        // batch traced again on the reference's tree.
+        const bool wideOnly = !(flags & (YART_REFERENCE_RULE | YART_REFERENCE_TREE)) && accel->hasWide;
+        for (int pass = 0; pass < 2 && st == YART_OK; ++pass) {
+            const unsigned f = flags | YART_STATIC_LAUNCH | (wideOnly ? (pass == 0 ? YART_RAYS_REGULAR : YART_REFERENCE_TREE) : 0u);
+            st = hits ? yart_intersect_closest_dev(accel, static_cast<YartRay*>(c.dev), n, reinterpret_cast<YartHit*>(dOut), f, c.stream)
+                      : yart_intersect_any_dev(accel, static_cast<YartRay*>(c.dev), n, reinterpret_cast<uint8_t*>(dOut), f, c.stream);
+            if (st == YART_OK) {
+                const hipError_t e = hipStreamSynchronize(c.stream);
+                if (e != hipSuccess) st = failHip(e, "hipStreamSynchronize");
+            }
+            if (!wideOnly || st != YART_OK) break;
+            bool unresolved = false;
+            if (hits) { const YartHit* h = reinterpret_cast<const YartHit*>(hOut); for (size_t i = 0; i < n && !unresolved; ++i) unresolved = h[i].prim == YART_PRIM_UNRESOLVED; }
+            else { const uint8_t* o = reinterpret_cast<const uint8_t*>(hOut); for (size_t i = 0; i < n && !unresolved; ++i) unresolved = o[i] == YART_OCC_UNRESOLVED; }
+            if (!unresolved) break;
         }
         if (st == YART_OK) std::memcpy(hits ? static_cast<void*>(hits) : static_cast<void*>(occluded), hOut, outBytes);
     } else {
@@ -794,6 +830,15 @@ int yart_build_host(const float* verts, size_t n_verts, const int32_t* tris, siz
     return YART_OK;
 }
 
+int yart_scene_cover(const float* verts, size_t n_verts, const float* spheres, size_t n_spheres, float out[10])
+{
+    if (!out || (n_verts && !verts) || (n_spheres && !spheres)) return fail(YART_ERR_INVALID_ARGUMENT, "yart_scene_cover: null argument");
+    const yart::Cover c = yart::sceneCover(verts, n_verts, spheres, n_spheres);
+    static_assert(sizeof(yart::Cover) == 40, "ten words");
+    std::memcpy(out, &c, sizeof c);
+    return YART_OK;
+}
+
 int yart_build_wide_host(const float* verts, size_t n_verts, const int32_t* tris, size_t n_tris,
                          const float* spheres, size_t n_spheres, int max_leaf,
                          void* nodes_out, size_t* n_nodes, void* rows_a_out, void* rows_bc_out, size_t* n_prims,
@@ -802,8 +847,10 @@ int yart_build_wide_host(const float* verts, size_t n_verts, const int32_t* tris
     yart::TriangleBvh tri;
     yart::WideBvh wide;
     std::string err;
+    if (n_tris >= (1u << 30) || n_spheres >= (1u << 30)) return fail(YART_ERR_INVALID_ARGUMENT, "wide BVH: more than 2^30 primitives of one kind");
     int st = yart::buildTriangleBvh(verts, n_verts, tris, n_tris, tri, err);
-    if (st == YART_OK) st = yart::buildWideBvh(verts, n_verts, tris, n_tris, tri, spheres, n_spheres, max_leaf, wide, err);
+    const yart::Cover cover = st == YART_OK ? yart::sceneCover(verts, n_verts, spheres, n_spheres) : yart::Cover{};
+    if (st == YART_OK) st = yart::buildWideBvh(verts, n_verts, tris, n_tris, tri, spheres, n_spheres, max_leaf, cover, wide, err);
     if (st != YART_OK) return fail(st, err);
     {
         // what is handed out is what the device would hold: packed (wide_build.h) and unpacked again

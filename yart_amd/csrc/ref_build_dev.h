@@ -6,6 +6,8 @@
 #include <cstdint>
 #include <string>
 
+#include "cover.h"
+
 namespace yart {
 
 struct DeviceRefTree {
@@ -44,6 +46,6 @@ struct DeviceSphereTree {
     void release();
 };
 // dSpheres: 4 floats per sphere on the device.  *useHost as above (NaN, too many one-sided splits).
-int buildSphereTreeDevice(const float* dSpheres, size_t nSpheres, DeviceSphereTree& out, bool* useHost, std::string& err);
+int buildSphereTreeDevice(const float* dSpheres, size_t nSpheres, const Cover& cover, DeviceSphereTree& out, bool* useHost, std::string& err);
 
 } // namespace yart

@@ -417,33 +417,10 @@ __global__ void __launch_bounds__(256) emitNodes(uint32_t total, uint32_t n, con
     }
 }
 
-// include/triaccel.h:54-108, the expressions of bvh_build.cpp projectTriangle
+// include/triaccel.h:54-108: cover.h projectRecord (the expressions of bvh_build.cpp projectTriangle)
 __device__ inline void projectTriangle(float out[12], const float* a, const float* b, const float* c, int32_t triIdx, int32_t meshIdx)
 {
-    const float ab[3] = { b[0] - a[0], b[1] - a[1], b[2] - a[2] };
-    const float ac[3] = { c[0] - a[0], c[1] - a[1], c[2] - a[2] };
-    const float nrm[3] = { ab[1] * ac[2] - ab[2] * ac[1],
-                           ab[2] * ac[0] - ab[0] * ac[2],
-                           ab[0] * ac[1] - ab[1] * ac[0] };
-    int k = 1;
-    const float ax = fabsf(nrm[0]), ay = fabsf(nrm[1]), az = fabsf(nrm[2]);
-    if (ax > ay) k = (ax > az) ? 0 : 2;
-    else if (az > ay) k = 2;
-    const int u = (k + 1) % 3, v = (k + 2) % 3;
-    const float proj[3] = { nrm[0] / nrm[k], nrm[1] / nrm[k], nrm[2] / nrm[k] };
-    out[0] = proj[u];
-    out[1] = proj[v];
-    out[2] = a[0] * proj[0] + a[1] * proj[1] + a[2] * proj[2];
-    out[3] = __int_as_float(k);
-    const float det = ab[u] * ac[v] - ab[v] * ac[u];
-    out[4] = -ab[v] / det;
-    out[5] = ab[u] / det;
-    out[6] = (ab[v] * a[u] - ab[u] * a[v]) / det;
-    out[7] = __int_as_float(triIdx);
-    out[8] = ac[v] / det;
-    out[9] = -ac[u] / det;
-    out[10] = -(ac[v] * a[u] - ac[u] * a[v]) / det;
-    out[11] = __int_as_float(meshIdx);
+    projectRecord(out, a, b, c, triIdx, meshIdx);
 }
 
 struct NanFix { uint32_t slot, tri; };
@@ -479,7 +456,7 @@ __global__ void __launch_bounds__(256) emitLeaves(const float4* __restrict__ rec
 
 // The engine's sphere tree (bvh_build.cpp buildSphereBvh): boxes widened by a relative margin so that the fp32 slab test
 // never rejects a ray the fp64 sphere test accepts, centre = the sphere's.  status[1]: a NaN (host builder's case).
-__global__ void __launch_bounds__(256) spherePrims(const float* __restrict__ spheres, uint32_t n, float4* __restrict__ primLo,
+__global__ void __launch_bounds__(256) spherePrims(const float* __restrict__ spheres, uint32_t n, Cover cover, float4* __restrict__ primLo,
                                                    float4* __restrict__ primHi, float4* __restrict__ rec, uint32_t* __restrict__ seg,
                                                    uint32_t* __restrict__ status)
 {
@@ -489,12 +466,9 @@ __global__ void __launch_bounds__(256) spherePrims(const float* __restrict__ sph
     const float r = fabsf(s[3]);
     float lo[3], hi[3];
     bool nan = !(r == r);
-    for (int a = 0; a < 3; ++a) {
-        const float margin = 1e-5f * (fabsf(s[a]) + r) + 1e-30f;
-        lo[a] = s[a] - r - margin;
-        hi[a] = s[a] + r + margin;
+    sphereBox(s, sqrt(sphereReff2(s, cover)), lo, hi);           // cover.h: everything the sphere test can accept
+    for (int a = 0; a < 3; ++a)
         nan = nan || !(s[a] == s[a]) || !(lo[a] == lo[a]) || !(hi[a] == hi[a]);
-    }
     if (nan) status[1] = 1u;
     seg[i] = 0u;
     primLo[i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
@@ -745,7 +719,7 @@ void DeviceSphereTree::release()
     pairs = records = index = nullptr;
 }
 
-int buildSphereTreeDevice(const float* dSpheres, size_t nSpheres, DeviceSphereTree& out, bool* useHost, std::string& err)
+int buildSphereTreeDevice(const float* dSpheres, size_t nSpheres, const Cover& cover, DeviceSphereTree& out, bool* useHost, std::string& err)
 {
     out = DeviceSphereTree{};
     *useHost = false;
@@ -755,7 +729,7 @@ int buildSphereTreeDevice(const float* dSpheres, size_t nSpheres, DeviceSphereTr
     int st = T.allocate(nSpheres, err);
     if (st != YART_OK) return st;
     const uint32_t n = T.n;
-    hipLaunchKernelGGL(spherePrims, dim3(blocks(nSpheres)), dim3(256), 0, nullptr, dSpheres, n, T.primLo, T.primHi, T.recA, T.seg, T.counters + 8);
+    hipLaunchKernelGGL(spherePrims, dim3(blocks(nSpheres)), dim3(256), 0, nullptr, dSpheres, n, cover, T.primLo, T.primHi, T.recA, T.seg, T.counters + 8);
     YART_HIP(hipGetLastError());
     uint32_t status[2];
     YART_HIP(hipMemcpy(status, T.counters + 8, sizeof status, hipMemcpyDeviceToHost));

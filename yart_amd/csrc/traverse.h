@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "bvh_build.h"
+#include "cover.h"
 
 namespace yart {
 
@@ -25,9 +26,18 @@ struct TraceParams {
                                 // than its list holds
     const uint32_t* deferList;  // their ray numbers, deferFlag[0] of them (at most deferCap)
     uint32_t deferCap;
-    uint32_t onlyDeferred;      // 1: trace only the rays the wide kernel deferred (!regularRay): the listed ones, or -- when the
-                                // list overflowed -- every ray of the batch that is not regularRay()
+    uint32_t onlyDeferred;      // 1: trace only the rays the wide kernel left behind: the listed ones, or -- when the list
+                                // overflowed -- every ray of the batch whose output holds the marker below
+    Cover cover;                // sphere tree: a ray that starts outside it gets its own pad on the sphere boxes
+    float sceneLo[3], sceneHi[3];   // bounds of the scene (for that pad)
 };
+
+// What the wide kernel leaves in the output of a ray it does not answer (irregular, outside the cover, an exact-t tie across
+// two leaves of the reference's tree) until the fix-up launches overwrite it; the fix-up sphere pass keeps the ray marked
+// for the triangle pass (kUnresolvedV in YartHit.v / kUnresolvedOcc).  include/yart_amd.h: YART_PRIM_UNRESOLVED.
+constexpr int32_t kUnresolvedPrim = INT32_MIN;
+constexpr uint8_t kUnresolvedOcc = 2;
+constexpr uint32_t kUnresolvedV = 0x7FC0DEFEu;
 
 // The wide-tree kernel (traverse_wide.hip) handles "regular" rays: finite origin, finite non-zero
 // 1/dir, minT == 0 (what the reference's Ray constructor sets, include/vector.h:244-249) and a maxT
@@ -66,10 +76,18 @@ struct WideParams {
     uint32_t laneCap;           // lanes of a wave that take rays (0 or 64: all): small batches spread over more, emptier waves
     uint32_t maxBlocksPerCU;    // 0 = as many as fit (8)
     uint32_t chunk;             // rays a wave takes from its range counter at a time (multiple of 64)
+    const float4* refPairs;     // the reference's triangle tree (sibling pairs, bvh_build.h): the box of a triangle's leaf there
+    const uint32_t* leafOfSlot; // leaf slot -> position (in float4 units) of that leaf's record in refPairs
+    Cover cover;                // rays that start outside it are left to the fix-up launches (cover.h)
+    float gridLo[3], gridHi[3]; // bounds of the (padded) primitive boxes: every node's grid lies inside
+    float gridExt[3];           // 1.25 x their extent (a node's 255 steps can overshoot its box by the step's rounding)
 };
 
 hipError_t launchTraceWide(const WideParams& P, bool any, bool count, bool persistent, int numCUs,
                            hipStream_t stream);
+
+// leafOfSlot[slot] = 4 * pair + 2 * child for every triangle slot of every leaf record of `pairs` (float4 units).
+hipError_t launchLeafOfSlot(const void* pairs, size_t numPairs, uint32_t* leafOfSlot, hipStream_t stream);
 
 // prim: 0 = triangle tree, 1 = sphere tree.
 hipError_t launchTrace(const TraceParams& P, int prim, bool any, bool prune, bool count,

@@ -49,6 +49,7 @@ struct RayState {
     float ox, oy, oz, dx, dy, dz;
     float ix, iy, iz;                // 1.0f / dir, the division of include/bbox.h:36 hoisted
     float tmin, tmax;
+    float pad;                       // sphere tree: widening of every box for a ray that starts outside the scene's cover
 };
 
 // include/bbox.h:30-50, operation for operation.  `tFar0` is ray.maxT in the
@@ -122,7 +123,7 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceParams P)
     const uint64_t laneBit = 1ull << lane;
 
     RayState r;
-    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = r.tmin = r.tmax = 0.0f;
+    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = r.tmin = r.tmax = r.pad = 0.0f;
     uint32_t cur = kIdle;            // encoded node reference, see bvh_build.h
     int sp = 0;
     bool live = false;               // lane owns a ray whose result is not written yet
@@ -144,7 +145,7 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceParams P)
     const int refillMin = (int)P.refillMin;
     const int nodeMin = (int)P.nodeMin;
     // Fix-up launch after the wide kernel: the rays it listed (or, when its list overflowed, every ray of the batch
-    // that is not regularRay()); nothing to do when it deferred none.  Wave-uniform.
+    // whose output still holds the wide kernel's marker); nothing to do when it deferred none.  Wave-uniform.
     uint32_t nRays = P.n;
     const uint32_t* perm = P.perm;
     bool listed = false;
@@ -172,13 +173,30 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceParams P)
         r.ox = a.x; r.oy = a.y; r.oz = a.z; r.tmin = a.w;
         r.dx = b.x; r.dy = b.y; r.dz = b.z; r.tmax = b.w;
         r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
-        if (P.onlyDeferred && !listed && regularRay(r.ox, r.oy, r.oz, r.tmin, r.dx, r.dy, r.dz, r.tmax)) {
-            live = false; cur = kIdle; sp = 0;           // the wide kernel has answered this ray
-            return;
+        if (P.onlyDeferred && !listed) {
+            bool marked;
+            if (ANY) marked = P.occluded[rayId] == kUnresolvedOcc;
+            else {
+                const float4 h = P.hits[rayId];
+                marked = __float_as_int(h.w) == kUnresolvedPrim || __float_as_uint(h.z) == kUnresolvedV;
+            }
+            if (!marked) { live = false; cur = kIdle; sp = 0; return; }        // the wide kernel has answered this ray
         }
         // The reference's sphere loop never looks at ray.minT (include/sphere.h:63-97 accepts
         // any t in (1e-4, current t)); only its triangle BVH culls by it (include/bbox.h:32,49).
-        if (PRIM == 1) r.tmin = 0.0f;
+        if (PRIM == 1) {
+            r.tmin = 0.0f;
+            // The sphere boxes hold what the sphere test can accept from a ray of the scene's cover (cover.h: radius
+            // sqrt(r^2 + 2^-20 D^2)).  A ray from outside it can have a longer |op|: all boxes are widened by
+            // 2^-10 x the distance from its origin to the far corner of the scene, which bounds the excess.
+            r.pad = 0.0f;
+            if (!coverHolds(P.cover, r.ox, r.oy, r.oz)) {
+                const float fx = fmaxf(fabsf(r.ox - P.sceneLo[0]), fabsf(P.sceneHi[0] - r.ox));
+                const float fy = fmaxf(fabsf(r.oy - P.sceneLo[1]), fabsf(P.sceneHi[1] - r.oy));
+                const float fz = fmaxf(fabsf(r.oz - P.sceneLo[2]), fabsf(P.sceneHi[2] - r.oz));
+                r.pad = 0x1.04p-10f * (fx + fy + fz);
+            }
+        }
         odd = !(finiteNonZero(r.ix) && finiteNonZero(r.iy) && finiteNonZero(r.iz) &&
                 fabsf(r.ox) < __builtin_inff() && fabsf(r.oy) < __builtin_inff() && fabsf(r.oz) < __builtin_inff() &&
                 r.tmin == r.tmin && r.tmax == r.tmax);
@@ -189,7 +207,7 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceParams P)
         cur = 0u;                    // pair 0 = { root, empty leaf }, axis bits 0
         if (P.chained) {             // triangle pass after the sphere pass
             if (ANY) {
-                if (P.occluded[rayId]) { live = false; cur = kIdle; }   // a sphere already occludes
+                if (P.occluded[rayId] == 1) { live = false; cur = kIdle; }   // a sphere already occludes (2: marked by the sphere pass of a fix-up)
             } else {
                 const float4 h = P.hits[rayId];                         // result of the sphere pass
                 tcur = h.x; prim = __float_as_int(h.w);
@@ -247,12 +265,13 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceParams P)
                 const uint32_t axis = cur >> 29;
                 const float bound = (PRUNE && !ANY) ? tcur * kCullSlack : r.tmax;      // slack: see traverse_wide.hip
                 bool h0, h1;
+                const float pd = PRIM == 1 ? r.pad : 0.0f;      // x - 0 is x: the triangle tree's boxes are the reference's own
                 if (__ballot(odd) != 0) {            // rare: some lane's ray can produce NaN plane distances
-                    h0 = slabExact(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, bound);
-                    h1 = slabExact(q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, r, bound);
+                    h0 = slabExact(q0.x - pd, q0.y - pd, q0.z - pd, q0.w + pd, q1.x + pd, q1.y + pd, r, bound);
+                    h1 = slabExact(q2.x - pd, q2.y - pd, q2.z - pd, q2.w + pd, q3.x + pd, q3.y + pd, r, bound);
                 } else {
-                    h0 = slabFast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, bound);
-                    h1 = slabFast(q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, r, bound);
+                    h0 = slabFast(q0.x - pd, q0.y - pd, q0.z - pd, q0.w + pd, q1.x + pd, q1.y + pd, r, bound);
+                    h1 = slabFast(q2.x - pd, q2.y - pd, q2.z - pd, q2.w + pd, q3.x + pd, q3.y + pd, r, bound);
                 }
                 const uint32_t r0 = __float_as_uint(q1.z), r1 = __float_as_uint(q3.z);
                 if (COUNT) cNodes += 2;
@@ -335,14 +354,16 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceParams P)
         // ------------------------------------------------------------ retire
         if (cur == kIdle && live) {
             live = false;
+            // the sphere pass of a fix-up keeps the ray marked for the triangle pass that follows it
+            const bool keepMark = PRIM == 1 && P.onlyDeferred;
             if (ANY) {
-                P.occluded[rayId] = (uint8_t)occ;
+                P.occluded[rayId] = (keepMark && !occ) ? kUnresolvedOcc : (uint8_t)occ;
             } else {
                 if (PRIM == 1) prim = (minS < 0) ? -1 : -((minS > maxL ? minS : maxL) + 2);
                 // include/scene.h:167: a hit only counts if t < ray.maxT
                 if (PRIM == 0 && !(tcur < r.tmax)) { prim = -1; }
                 if (prim == -1) { hu = 0.0f; hv = 0.0f; }
-                P.hits[rayId] = make_float4(tcur, hu, hv, __int_as_float(prim));
+                P.hits[rayId] = make_float4(tcur, hu, keepMark ? __uint_as_float(kUnresolvedV) : hv, __int_as_float(prim));
             }
             if (COUNT) {
                 uint32_t* c = P.counts + (size_t)rayId * 4;

@@ -18,11 +18,18 @@
 //              scan over Scene::shapes_ is reproduced by the order-independent rule of traverse.hip
 //   result     the triangle iff its t is strictly below the sphere's float t, else the sphere
 //              (include/scene.h:142-167: spheres first, triangles must be strictly closer)
-// Exact-t ties between two different triangles go to the lower leaf slot (what the reference's
-// in-leaf order gives for coplanar duplicates; ties across ITS leaves depend on its visiting order
-// and are not reproducible with another tree: see DESIGN.md, parity bar).
+// Exact-t ties between two different triangles: the reference keeps the first one ITS traversal finds.  Inside one
+// of its leaves that is the lower slot, which this kernel can tell (leafOfSlot); a tie across two of its leaves depends
+// on its visiting order, so such a ray is handed to the fix-up launches, which walk the reference's tree in that order.
 //
-// Rays that are not regularRay() (traverse.h) are left to the fix-up launch on the reference tree.
+// False positives of the reference's tests (cover.h): every primitive's box holds all its test can accept from a
+// covered ray, and a triangle hit within the triangle's error band of an edge counts only if the ray passes the box
+// of the triangle's leaf in the reference's tree (include/bbox.h:30-50) -- the condition under which the reference
+// reaches that test at all.
+//
+// Rays that are not regularRay() (traverse.h) or start outside the scene's cover are left to the fix-up launches on the
+// reference tree; so are the tied rays above.  Such a ray's output holds a marker (kUnresolvedPrim / kUnresolvedOcc)
+// until the fix-up launch overwrites it.
 // Built with -ffp-contract=off: every tested expression rounds as the reference's C++ does.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -62,7 +69,20 @@ __device__ __forceinline__ float sel3(int i, float a, float b, float c)
 
 struct WRay {
     float ox, oy, oz, dx, dy, dz, ix, iy, iz, tmax;
+    float cm;           // cull margin: what the rounding of slab4's plane distances can amount to for this ray
 };
+
+// include/bbox.h:30-50 for a regular ray (no NaN plane distance, minT = 0): the reference's own slab arithmetic
+// against [0, maxT], on the box of a leaf of ITS tree (q0 = lo.xyz, hi.x; q1 = hi.y, hi.z).
+__device__ __forceinline__ bool slabRef(const float4& q0, const float4& q1, const WRay& r)
+{
+    const float ax = (q0.x - r.ox) * r.ix, bx = (q0.w - r.ox) * r.ix;
+    const float ay = (q0.y - r.oy) * r.iy, by = (q1.x - r.oy) * r.iy;
+    const float az = (q0.z - r.oz) * r.iz, bz = (q1.y - r.oz) * r.iz;
+    const float tNear = fmaxf(fmaxf(0.0f, fminf(ax, bx)), fmaxf(fminf(ay, by), fminf(az, bz)));
+    const float tFar = fminf(fminf(r.tmax, fmaxf(ax, bx)), fminf(fmaxf(ay, by), fmaxf(az, bz)));
+    return !(tFar < tNear) && (tFar > 0.0f) && (tNear < r.tmax);
+}
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -133,7 +153,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
     const uint64_t laneBit = 1ull << lane;
 
     WRay r;
-    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = r.tmax = 0.0f;
+    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = r.tmax = r.cm = 0.0f;
     uint32_t cur = kIdle;
     uint32_t pend = kIdle;                         // a triangle leaf set aside while the lane keeps descending
     uint32_t pendS = kIdle;                        // a sphere leaf set aside likewise: the sphere test is double-precision code
@@ -175,22 +195,41 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
         return ovf[sp - kLdsStack];                           // load there, instead of one flat load for both
     };
 
+    // A ray this kernel does not answer: the fix-up launches on the reference tree do, taking the listed rays only; a
+    // batch with more such rays than the list holds is scanned whole for the marker left in the ray's output (no
+    // atomic once the list is full).
+    auto deferRay = [&](uint32_t id) {
+        uint32_t c = __hip_atomic_load(P.deferFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c < P.deferCap) c = atomicAdd(P.deferFlag, 1u);
+        if (c < P.deferCap) P.deferList[c] = id;
+        else P.deferFlag[1] = 1u;
+        if (ANY) P.occluded[id] = kUnresolvedOcc;
+        else P.hits[id] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(kUnresolvedPrim));
+    };
+
     auto startRay = [&](uint32_t slot) {
         rayId = P.perm ? P.perm[slot] : slot;
         const float4 a = P.rays[(size_t)rayId * 2 + 0];
         const float4 b = P.rays[(size_t)rayId * 2 + 1];
-        if (!regularRay(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w)) {
-            // answered by the fix-up launches on the reference tree, which take the listed rays only; a batch with
-            // more such rays than the list holds is scanned whole (no atomic once the list is full)
-            uint32_t c = __hip_atomic_load(P.deferFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (c < P.deferCap) c = atomicAdd(P.deferFlag, 1u);
-            if (c < P.deferCap) P.deferList[c] = rayId;
-            else P.deferFlag[1] = 1u;
+        if (!regularRay(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w) || !coverHolds(P.cover, a.x, a.y, a.z)) {
+            deferRay(rayId);
             return;
         }
         r.ox = a.x; r.oy = a.y; r.oz = a.z;
         r.dx = b.x; r.dy = b.y; r.dz = b.z; r.tmax = b.w;
         r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
+        {
+            // slab4's plane distance t = q B + A, A = (origin_node - o) / d, B = step / d, carries up to 2^-22 (|A| + 255 |B|)
+            // of rounding; every node's grid lies inside [gridLo, gridHi], so per axis |A| + 255 |B| <= (distance of o from
+            // the far side of that box + 1.25 x its extent) / |d|.  Nodes are culled against the best hit plus twice that
+            // (once per ray, not per node: for a ray nearly parallel to an axis the margin is wide and it culls less).
+            const float fx = fmaxf(fabsf(r.ox - P.gridLo[0]), fabsf(P.gridHi[0] - r.ox)) + P.gridExt[0];
+            const float fy = fmaxf(fabsf(r.oy - P.gridLo[1]), fabsf(P.gridHi[1] - r.oy)) + P.gridExt[1];
+            const float fz = fmaxf(fabsf(r.oz - P.gridLo[2]), fabsf(P.gridHi[2] - r.oz)) + P.gridExt[2];
+            r.cm = 0x1p-21f * fmaxf(fmaxf(fabsf(r.ix) * fx, fabsf(r.iy) * fy), fabsf(r.iz) * fz);
+            // a product that overflows: so could A or 255 B, and slab4 would see infinite planes of the wrong sign
+            if (!(r.cm < __builtin_inff())) { deferRay(rayId); return; }
+        }
         tTri = r.tmax; hu = 0.0f; hv = 0.0f; primTri = -1;
         F = __builtin_inff(); minS = -1; maxL = -1; occ = 0;
         cNodes = 0; cTri = 0; cSph = 0; cStage2 = 0;
@@ -273,7 +312,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
                 // latency starts earlier.  C4 4.77 -> 4.68 ms, s = 0.01 7.81 -> 7.50 ms; the level (1..3) does not
                 // matter, and lowering it for the primitive tests as well gives half of that back.
                 __builtin_amdgcn_s_setprio(0);
-                const float bound = (ANY ? r.tmax : (SPH ? fminf(tTri, F) : tTri)) * kCullSlack;
+                const float bound = __builtin_fmaf(ANY ? r.tmax : (SPH ? fminf(tTri, F) : tTri), kCullSlack, r.cm);
                 float tn[4];
                 uint32_t rf[4];
                 const uint32_t blk = __float_as_uint(q2.z), offs = __float_as_uint(q2.w);
@@ -305,7 +344,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
         { const uint64_t pm = __ballot(pend != kIdle); if (pm) { ++stLeafSteps; stLeafLanes += __popcll(pm); } ++stIters; stLive += __popcll(__ballot(live));
           const uint64_t sm = __ballot(sphNow && pendS != kIdle); if (sm) { ++stSphSteps; stSphLanes += __popcll(sm); } }
 #endif
-        bool stop = false;
+        bool stop = false, unresolved = false;
         if (pend != kIdle) {
             const uint32_t leaf = pend;
             pend = kIdle;
@@ -324,14 +363,12 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
                     const float nd = 1.0f / (dk + A.x * du + A.y * dv);
                     const float t = (A.z - ok - A.x * ou - A.y * ov) * nd;
                     const float bound = ANY ? r.tmax : (SPH ? fminf(tTri, F) : tTri);
-                    // The reference keeps the FIRST triangle it finds at a given t (`info->t > t` is
-                    // strict); coplanar duplicates sit in one of its leaves in slot order, so the lowest
-                    // slot wins there.  An exact tie therefore goes to the lower slot here, whatever
-                    // order this tree finds them in.
-                    const bool tie = !ANY && t == tTri && (int32_t)(kw >> 2) < primTri;
+                    const uint32_t slot = (kw & kPackSlotMask) >> 2;
+                    // an exact tie with the triangle held so far is looked at too (below)
+                    const bool tie = !ANY && t == tTri && primTri >= 0 && (int32_t)slot != primTri;
                     if (!((bound > t || tie) && t > 0.0001f)) break;
                     // second stage: rows b and c of the reference's TriAccel record of this slot
-                    const float4* ta = P.triaccel + (size_t)(kw >> 2) * 3;
+                    const float4* ta = P.triaccel + (size_t)slot * 3;
                     const float4 B = ta[1], C = ta[2];
                     if (COUNT) ++cStage2;
                     const float phu = ou + t * du;
@@ -341,12 +378,30 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
                     const float mue = phu * C.x + phv * C.y + C.z;
                     if (mue < 0.0f) break;
                     if (lambda + mue > 1.0f) break;
+                    // Accepted by the reference's test.  Within the triangle's error band of an edge (cover.h) the hit
+                    // point may lie outside the triangle, and then outside the box of the triangle's leaf in the
+                    // reference's tree: the reference finds this hit only if the ray passes that box.
+                    if (kw >> kPackBandShift) {
+                        if (fminf(fminf(lambda, mue), 1.0f - (lambda + mue)) < bandOfClass(kw >> kPackBandShift)) {
+                            const float4* lb = P.refPairs + P.leafOfSlot[slot];
+                            const float4 b0 = lb[0], b1 = lb[1];
+                            if (!slabRef(b0, b1, r)) break;
+                        }
+                    }
                     if (ANY) { occ = 1; stop = true; break; }
+                    if (tie) {
+                        // The reference keeps the FIRST triangle it finds at a given t (`info->t > t` is strict).  Two
+                        // triangles of one of its leaves are tested in slot order: the lower slot wins.  Across two of
+                        // its leaves its visiting order decides: left to the fix-up launches.
+                        if (P.leafOfSlot[slot] != P.leafOfSlot[primTri]) { unresolved = true; break; }
+                        if ((int32_t)slot > primTri) break;
+                    }
                     tTri = t; hv = lambda; hu = mue;       // include/triaccel.h:194-196
-                    primTri = (int32_t)(kw >> 2);
+                    primTri = (int32_t)slot;
                 } while (false);
             }
         }
+        if (unresolved) { deferRay(rayId); live = false; cur = kIdle; sp = 0; pend = kIdle; pendS = kIdle; }
         if (SPH && sphNow && pendS != kIdle && !stop) {
             const float4* row = P.units + (pendS >> 2);
             pendS = kIdle;
@@ -467,7 +522,26 @@ hipError_t launchW(const WideParams& P, bool persistent, int numCUs, hipStream_t
     return hipGetLastError();
 }
 
+// Where the record of a triangle's leaf sits in the reference's pair array (the near-edge check and the tie rule above).
+__global__ void __launch_bounds__(256) leafOfSlotKernel(const uint4* __restrict__ pairs, uint32_t numPairs, uint32_t* __restrict__ leafOfSlot)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;          // one child record per thread
+    if (i >= numPairs * 2u) return;
+    const uint32_t ref = pairs[(size_t)i * 2 + 1].z;             // DevNodeRec::ref (bvh_build.h)
+    if (!(ref & kLeafBit)) return;
+    const uint32_t slot0 = (ref & 0x7FFFFFFFu) >> 3, cnt = ref & 7u;
+    for (uint32_t k = 0; k < cnt; ++k) leafOfSlot[slot0 + k] = i * 2u;
+}
+
 } // namespace
+
+hipError_t launchLeafOfSlot(const void* pairs, size_t numPairs, uint32_t* leafOfSlot, hipStream_t stream)
+{
+    if (numPairs == 0) return hipSuccess;
+    const uint32_t n = (uint32_t)numPairs * 2u;
+    hipLaunchKernelGGL(leafOfSlotKernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, static_cast<const uint4*>(pairs), (uint32_t)numPairs, leafOfSlot);
+    return hipGetLastError();
+}
 
 hipError_t launchTraceWide(const WideParams& P, bool any, bool count, bool persistent, int numCUs,
                            hipStream_t stream)

@@ -2,6 +2,7 @@
 // thread pool, collapse to four children per node, depth-first emission of 64-byte quantised nodes and
 // two-stage leaf rows.
 #include "wide_build.h"
+#include "cover.h"
 #include "task_pool.h"
 
 #include <algorithm>
@@ -328,8 +329,8 @@ float bitsFloat(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 class Emitter {
 public:
     Emitter(const BNodePool& nodes, const std::vector<BPrim>& prims, const TriangleBvh& tri,
-            const float* spheres, WideBvh& out)
-        : nodes_(nodes), prims_(prims), tri_(tri), spheres_(spheres), out_(out) { }
+            const float* spheres, const std::vector<uint8_t>& bandClass, WideBvh& out)
+        : nodes_(nodes), prims_(prims), tri_(tri), spheres_(spheres), bandClass_(bandClass), out_(out) { }
 
     bool tooManyPrims = false;
     bool planned_ = false;              // follow BNode::take (planCollapse) instead of the greedy collapse
@@ -557,7 +558,8 @@ private:
                 B[0] = bitsFloat(ids[i]);
             } else {
                 const YartTriAccel& ta = tri_.triaccel[ids[i]];
-                A[0] = ta.n_u; A[1] = ta.n_v; A[2] = ta.n_d; A[3] = bitsFloat(static_cast<uint32_t>(ta.k) | (ids[i] << 2));
+                A[0] = ta.n_u; A[1] = ta.n_v; A[2] = ta.n_d;
+                A[3] = bitsFloat(static_cast<uint32_t>(ta.k) | (ids[i] << 2) | (static_cast<uint32_t>(bandClass_[ids[i]]) << kPackBandShift));
                 B[0] = ta.b_u; B[1] = ta.b_v; B[2] = ta.b_d;
                 C[0] = ta.c_u; C[1] = ta.c_v; C[2] = ta.c_d;
             }
@@ -570,6 +572,7 @@ private:
     const std::vector<BPrim>& prims_;
     const TriangleBvh& tri_;
     const float* spheres_;
+    const std::vector<uint8_t>& bandClass_;          // per leaf slot: class of the triangle's error band (cover.h)
     WideBvh& out_;
     std::vector<Job> jobs_;
     uint32_t jobSpan_ = 0;
@@ -803,7 +806,7 @@ bool unpackWide(const uint32_t* words, size_t numUnits, const YartTriAccel* tria
                 std::memcpy(&out.rowsA[first * 4], row, 16);
                 if (sph) std::memcpy(&out.rowsBC[first * 8], row + 4, 4);
                 else {
-                    const size_t slot = row[3] >> 2;
+                    const size_t slot = (row[3] & kPackSlotMask) >> 2;
                     if (slot >= nTriangles) return false;
                     const YartTriAccel& ta = triaccel[slot];
                     float* B = &out.rowsBC[first * 8];
@@ -823,9 +826,84 @@ bool unpackWide(const uint32_t* words, size_t numUnits, const YartTriAccel* tria
     return done == out.nodes.size();
 }
 
+Cover sceneCover(const float* verts, size_t nVerts, const float* spheres, size_t nSpheres)
+{
+    // bounds of the finite vertex coordinates and sphere extents, smallest sphere radius
+    struct Acc { float lo[3], hi[3]; float rMin; bool any; };
+    const float inf = std::numeric_limits<float>::infinity();
+    const Acc empty{ { inf, inf, inf }, { -inf, -inf, -inf }, inf, false };
+    std::mutex mu;
+    Acc all = empty;
+    auto merge = [&](const Acc& a) {
+        std::lock_guard<std::mutex> lock(mu);
+        for (int c = 0; c < 3; ++c) { all.lo[c] = std::min(all.lo[c], a.lo[c]); all.hi[c] = std::max(all.hi[c], a.hi[c]); }
+        all.rMin = std::min(all.rMin, a.rMin);
+        all.any = all.any || a.any;
+    };
+    parallelChunks(nVerts, buildThreads(), size_t(1) << 18, [&](size_t b, size_t e) {
+        Acc a = empty;
+        for (size_t i = b; i < e; ++i)
+            for (int c = 0; c < 3; ++c) {
+                const float x = verts[i * 3 + c];
+                if (!(std::fabs(x) < inf)) continue;
+                a.lo[c] = std::min(a.lo[c], x); a.hi[c] = std::max(a.hi[c], x); a.any = true;
+            }
+        merge(a);
+    });
+    parallelChunks(nSpheres, buildThreads(), size_t(1) << 18, [&](size_t b, size_t e) {
+        Acc a = empty;
+        for (size_t i = b; i < e; ++i) {
+            const float* s = spheres + i * 4;
+            const float r = std::fabs(s[3]);
+            if (!(r < inf)) continue;
+            a.rMin = std::min(a.rMin, r);
+            for (int c = 0; c < 3; ++c) {
+                if (!(std::fabs(s[c]) < inf)) continue;
+                a.lo[c] = std::min(a.lo[c], s[c] - r); a.hi[c] = std::max(a.hi[c], s[c] + r); a.any = true;
+            }
+        }
+        merge(a);
+    });
+    bool have = all.any;
+    for (int c = 0; c < 3; ++c) {
+        if (!(all.lo[c] <= all.hi[c])) { all.lo[c] = all.hi[c] = 0.0f; }      // an axis without a finite coordinate
+        if (!(std::fabs(all.lo[c]) < inf && std::fabs(all.hi[c]) < inf)) have = false;
+    }
+    // Outliers: the error bounds grow with the size of the cover (cover.h), so one vertex far from everything else
+    // (a sky dome, a stray coordinate of 1e38) must not set it.  The cover is built around where the primitives ARE: per
+    // axis the median of a sample of the vertices and sphere centres, +- 64 x the widest median absolute deviation of
+    // the three axes (a uniformly filled box has a deviation of a quarter of its side: 16 sides each way), and never
+    // beyond the true bounds.  Rays that start outside it take the fix-up path (traverse.hip).
+    const char* trim = std::getenv("YART_COVER_TRIM");
+    if (have && !(trim && trim[0] == '0')) {
+        constexpr size_t kSample = 4096;
+        std::vector<float> q[3];
+        auto take = [&](const float* p) { for (int c = 0; c < 3; ++c) if (std::fabs(p[c]) < inf) q[c].push_back(p[c]); };
+        const size_t sv = std::max<size_t>(1, nVerts / kSample), ss = std::max<size_t>(1, nSpheres / kSample);
+        for (size_t i = 0; i < nVerts; i += sv) take(verts + i * 3);
+        for (size_t i = 0; i < nSpheres; i += ss) take(spheres + i * 4);
+        float med[3], spread = 0.0f;
+        bool ok = true;
+        for (int c = 0; c < 3; ++c) {
+            if (q[c].empty()) { ok = false; break; }
+            std::sort(q[c].begin(), q[c].end());
+            med[c] = q[c][q[c].size() / 2];
+            for (float& x : q[c]) x = std::fabs(x - med[c]);
+            std::sort(q[c].begin(), q[c].end());
+            spread = std::max(spread, q[c][q[c].size() / 2]);
+        }
+        if (ok && spread > 0.0f && spread < inf)
+            for (int c = 0; c < 3; ++c) {
+                all.lo[c] = std::max(all.lo[c], med[c] - 64.0f * spread);
+                all.hi[c] = std::min(all.hi[c], med[c] + 64.0f * spread);
+            }
+    }
+    return makeCover(all.lo, all.hi, have, nSpheres, all.rMin < inf ? all.rMin : 0.0f);
+}
+
 int buildWideBvh(const float* verts, size_t nVerts, const int32_t* tris, size_t nTris,
                  const TriangleBvh& tri, const float* spheres, size_t nSpheres,
-                 int maxLeaf, WideBvh& out, std::string& err)
+                 int maxLeaf, const Cover& cover, WideBvh& out, std::string& err)
 {
     (void)nVerts;
     maxLeaf = 1;            // one primitive per leaf: what the packed format holds (wide_build.h)
@@ -841,16 +919,18 @@ int buildWideBvh(const float* verts, size_t nVerts, const int32_t* tris, size_t 
     const int presplit = std::max(1, std::min(8, envInt("YART_WIDE_PRESPLIT", 1)));
     const size_t perTri = static_cast<size_t>(presplit);
     std::vector<BPrim> prims(nTris * perTri + nSpheres);
+    std::vector<uint8_t> bandClass(nTris, 0);           // by leaf slot
     parallelChunks(nTris, buildThreads(), size_t(1) << 16, [&](size_t b, size_t e) {
         for (size_t i = b; i < e; ++i) {
             const int32_t* t = tris + i * 5;
             const float* vv[3] = { verts + static_cast<size_t>(t[0]) * 3, verts + static_cast<size_t>(t[1]) * 3,
                                    verts + static_cast<size_t>(t[2]) * 3 };
             BPrim whole;
-            std::memcpy(whole.lo, vv[0], 12);
-            std::memcpy(whole.hi, vv[0], 12);
-            for (int k = 1; k < 3; ++k)
-                for (int a = 0; a < 3; ++a) { whole.lo[a] = std::min(whole.lo[a], vv[k][a]); whole.hi[a] = std::max(whole.hi[a], vv[k][a]); }
+            // the triangle's box grown by the error band of its Wald test (cover.h): every point the test can accept
+            uint32_t cls = 0;
+            const uint32_t slot = tri.slotOfInput[i];
+            triBand(reinterpret_cast<const float*>(&tri.triaccel[slot]), vv[0], vv[1], vv[2], cover, whole.lo, whole.hi, cls);
+            bandClass[slot] = static_cast<uint8_t>(cls);
             whole.id = static_cast<uint32_t>(i);
             BPrim* out = &prims[i * perTri];
             int made = 0;
@@ -908,22 +988,18 @@ int buildWideBvh(const float* verts, size_t nVerts, const int32_t* tris, size_t 
     });
     parallelChunks(nSpheres, buildThreads(), size_t(1) << 16, [&](size_t b, size_t e) {
         for (size_t i = b; i < e; ++i) {
-            // extents widened by a relative margin: the fp32 slab test must never reject a ray the
-            // fp64 sphere test (include/sphere.h:63-97) accepts
+            // the box of everything the fp64 sphere test (include/sphere.h:63-97) can accept from a covered ray: radius
+            // sqrt(r^2 + 2^-20 D^2) (cover.h), rounded outward
             const float* s = spheres + i * 4;
-            const float r = std::fabs(s[3]);
             BPrim& p = prims[nTris * perTri + i];
-            for (int a = 0; a < 3; ++a) {
-                const float margin = 1e-5f * (std::fabs(s[a]) + r) + 1e-30f;
-                p.lo[a] = s[a] - r - margin;
-                p.hi[a] = s[a] + r + margin;
-                p.c[a] = s[a];
-            }
+            sphereBox(s, std::sqrt(sphereReff2(s, cover)), p.lo, p.hi);
+            for (int a = 0; a < 3; ++a) p.c[a] = s[a];
+            if (!sphereFinite(s)) p.lo[0] = std::numeric_limits<float>::quiet_NaN();       // never accepted: left out below
             p.id = kSphereId | static_cast<uint32_t>(i);
         }
     });
-    // NaN coordinates would poison the binning arithmetic; such primitives can never be hit
-    // (every comparison of their tests fails), so they are left out of the tree.
+    // NaN and infinite coordinates would poison the binning arithmetic; such primitives can never be hit
+    // (cover.h: triBand, sphereFinite), so they are left out of the tree.
     prims.erase(std::remove_if(prims.begin(), prims.end(), [](const BPrim& p) {
         for (int a = 0; a < 3; ++a) if (!(p.lo[a] <= p.hi[a])) return true;
         return false;
@@ -938,13 +1014,17 @@ int buildWideBvh(const float* verts, size_t nVerts, const int32_t* tris, size_t 
         const char* greedy = std::getenv("YART_WIDE_GREEDY_COLLAPSE");
         const bool plan = !(greedy && greedy[0] == '1');
         const double t1 = now();
-        Emitter e(b.nodes(), prims, tri, spheres, out);
+        Emitter e(b.nodes(), prims, tri, spheres, bandClass, out);
         e.planned_ = plan;
         e.run(prims.size() < kSpawnAbove ? 1u : buildThreads());
         if (timing) fprintf(stderr, "wide build: binary SAH %.2fs, collapse+emit %.2fs (%zu nodes, depth %d)\n", t1 - t0, now() - t1, out.nodes.size(), out.depth);
         if (e.tooManyPrims) {
             err = "wide BVH: more than 2^27 - 1 primitives";
             return YART_ERR_INVALID_ARGUMENT;
+        }
+        if (!prims.empty()) {
+            std::memcpy(out.rootLo, b.nodes()[0].box.lo, 12);
+            std::memcpy(out.rootHi, b.nodes()[0].box.hi, 12);
         }
         if (3 * out.depth + 1 <= kWideStack) {
             relayout(out, envInt("YART_WIDE_LAYOUT", 0));

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "bvh_build.h"
+#include "cover.h"
 
 namespace yart {
 
@@ -65,6 +66,7 @@ struct WideBvh {
     std::vector<float> rowsBC;          // 8 floats per primitive
     int depth = 0;                      // wide levels (root = 1)
     size_t numLeaves = 0;
+    float rootLo[3] = { 0, 0, 0 }, rootHi[3] = { 0, 0, 0 };     // bounds of all (padded) primitive boxes: every node's grid lies inside
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -81,11 +83,14 @@ struct WideBvh {
 //     unit 2   upper planes y, z | block: (unit index of the children block) << 2 | offsets: byte c = (unit offset of
 //              child c inside the block) << 2 | class of child c
 //   reference = (unit index << 2) | class;  class bit 0 = leaf, bit 1 = sphere;  the root node is reference 0
-//   triangle leaf, 1 unit:  n_u, n_v, n_d, bits(k | slot << 2)   -- second stage: rows b and c of TriAccel record `slot`
-//                           of the reference's leaf-ordered array (the accel's dTriAccel), nothing is duplicated
+//   triangle leaf, 1 unit:  n_u, n_v, n_d, bits(k | slot << 2 | band << 29)   -- second stage: rows b and c of TriAccel
+//                           record `slot` of the reference's leaf-ordered array (the accel's dTriAccel), nothing is
+//                           duplicated; band = class of the triangle's error band (cover.h: triBand, bandOfClass)
 //   sphere leaf, 2 units:   cx, cy, cz, radius | sphere number, 0, 0, 0
 // Leaves hold one primitive.  An unused child slot keeps its inverted box (never entered); its offset byte is 0.
 constexpr uint32_t kPackLeaf = 1u, kPackSphere = 2u;
+constexpr uint32_t kPackBandShift = 29;                  // fourth word of a triangle row: k | slot << 2 | band class << 29
+constexpr uint32_t kPackSlotMask = 0x1FFFFFFCu;
 constexpr size_t kPackMaxUnits = (size_t(1) << 30) - 2;
 
 struct PackedWide {
@@ -107,8 +112,12 @@ bool unpackWide(const uint32_t* words, size_t numUnits, const YartTriAccel* tria
 // `tri` supplies the reference-order TriAccel records and, per input triangle, its leaf slot.
 // maxLeaf is kept for the callers that pass it; leaves hold one primitive (the packed format has no count, and
 // larger leaves measured slower on MI355X: tools/exp_wide.py).  Returns YART_OK or an error status with `err` set.
+// `cover` (cover.h): the rays the primitives' boxes are padded for.
 int buildWideBvh(const float* verts, size_t nVerts, const int32_t* tris, size_t nTris,
                  const TriangleBvh& tri, const float* spheres, size_t nSpheres,
-                 int maxLeaf, WideBvh& out, std::string& err);
+                 int maxLeaf, const Cover& cover, WideBvh& out, std::string& err);
+
+// The cover of a scene: bounds of its finite vertex coordinates and sphere extents, widened (cover.h: makeCover).
+Cover sceneCover(const float* verts, size_t nVerts, const float* spheres, size_t nSpheres);
 
 } // namespace yart

@@ -32,6 +32,7 @@
 #include "../../include/yart_amd.h"
 #include "wide_build.h"
 #include "wide_build_dev.h"
+#include "cover.h"
 
 namespace yart {
 namespace {
@@ -61,7 +62,7 @@ __host__ __device__ inline float fromOrdered(uint32_t k)
 
 // bounds[0..2] = min of centres (ordered bits), [3..5] = max, [6] = valid primitives
 __global__ void __launch_bounds__(256) primBoxes(const float* __restrict__ verts, const int32_t* __restrict__ tris, uint32_t nTris,
-                                                 const float* __restrict__ spheres, uint32_t nSpheres, uint32_t nVerts,
+                                                 const float* __restrict__ spheres, uint32_t nSpheres, uint32_t nVerts, Cover cover,
                                                  float4* __restrict__ lo, float4* __restrict__ hi, uint32_t* __restrict__ bounds)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -86,15 +87,18 @@ __global__ void __launch_bounds__(256) primBoxes(const float* __restrict__ verts
                 const float* v = verts + (size_t)(uint32_t)t[k] * 3;
                 if (!(v[0] == v[0] && v[1] == v[1] && v[2] == v[2])) valid = false;
             }
+        if (valid) {
+            // grown by the error band of the triangle's Wald test, as wide_build.cpp does (cover.h)
+            const float *va = verts + (size_t)(uint32_t)t[0] * 3, *vb = verts + (size_t)(uint32_t)t[1] * 3, *vc = verts + (size_t)(uint32_t)t[2] * 3;
+            float rec[12];
+            uint32_t cls;
+            projectRecord(rec, va, vb, vc, t[4], t[3]);
+            triBand(rec, va, vb, vc, cover, l, h, cls);
+        }
     } else if (i < n) {
         const float* s = spheres + (size_t)(i - nTris) * 4;
-        const float r = fabsf(s[3]);
-        for (int a = 0; a < 3; ++a) {
-            const float margin = 1e-5f * (fabsf(s[a]) + r) + 1e-30f;          // as wide_build.cpp
-            l[a] = s[a] - r - margin;
-            h[a] = s[a] + r + margin;
-        }
-        valid = true;
+        sphereBox(s, sqrt(sphereReff2(s, cover)), l, h);        // as wide_build.cpp
+        valid = sphereFinite(s);
     }
     if (valid) for (int a = 0; a < 3; ++a) if (!(l[a] <= h[a])) valid = false;      // NaN: can never be hit, left out
     if (i < n) {
@@ -633,7 +637,8 @@ __global__ void __launch_bounds__(256) packNodes(const WideNode* __restrict__ no
 // leaf rows: the reference's TriAccel bits of the triangle's slot / the sphere record, at the unit packAssign chose
 __global__ void __launch_bounds__(256) leafRows(const uint32_t* __restrict__ sortedIds, uint32_t n, uint32_t nTris,
                                                 const uint32_t* __restrict__ slotOfInput, const float4* __restrict__ triaccel,
-                                                const float4* __restrict__ spheres, const uint32_t* __restrict__ leafUnit, float4* __restrict__ units)
+                                                const float4* __restrict__ spheres, const float* __restrict__ verts, const int32_t* __restrict__ tris,
+                                                Cover cover, const uint32_t* __restrict__ leafUnit, float4* __restrict__ units)
 {
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
     if (r >= n) return;
@@ -641,9 +646,15 @@ __global__ void __launch_bounds__(256) leafRows(const uint32_t* __restrict__ sor
     float4* row = units + leafUnit[r];
     if (p < nTris) {
         const uint32_t slot = slotOfInput[p];
-        const float4 a = triaccel[(size_t)slot * 3 + 0];
+        const float4 a = triaccel[(size_t)slot * 3 + 0], b = triaccel[(size_t)slot * 3 + 1], c = triaccel[(size_t)slot * 3 + 2];
         const uint32_t k = __float_as_uint(a.w);                        // TriAccel::k (0..2)
-        row[0] = make_float4(a.x, a.y, a.z, __uint_as_float((k & 3u) | (slot << 2)));
+        // class of the triangle's error band (cover.h), from the record itself
+        const float rec[12] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w };
+        const int32_t* t = tris + (size_t)p * 5;
+        float l[3], h[3];
+        uint32_t cls;
+        triBand(rec, verts + (size_t)(uint32_t)t[0] * 3, verts + (size_t)(uint32_t)t[1] * 3, verts + (size_t)(uint32_t)t[2] * 3, cover, l, h, cls);
+        row[0] = make_float4(a.x, a.y, a.z, __uint_as_float((k & 3u) | (slot << 2) | (cls << kPackBandShift)));
     } else {
         const uint32_t s = p - nTris;
         row[0] = spheres[s];
@@ -676,6 +687,8 @@ struct DeviceWideBuilder::State {
     float* dVerts = nullptr;
     int32_t* dTris = nullptr;
     WideNode* wide = nullptr;
+    Cover cover;
+    float rootLo[3] = { 0, 0, 0 }, rootHi[3] = { 0, 0, 0 };     // bounds of the padded primitive boxes = of every node
     std::chrono::steady_clock::time_point t0;
     double msTopology = 0.0;
 };
@@ -685,7 +698,7 @@ DeviceWideBuilder::~DeviceWideBuilder() { delete state_; }
 
 // Phase 1: everything that needs only the scene -- boxes, sort, topology, fit, plan, wide nodes.
 int DeviceWideBuilder::topology(const float* verts, size_t nVerts, const int32_t* tris, size_t nTris, const float* spheres,
-                                size_t nSpheres, std::string& err)
+                                size_t nSpheres, const Cover& cover, std::string& err)
 {
     delete state_;
     state_ = nullptr;
@@ -696,6 +709,7 @@ int DeviceWideBuilder::topology(const float* verts, size_t nVerts, const int32_t
     st->t0 = std::chrono::steady_clock::now();
     st->nTris = nTris;
     st->nSpheres = nSpheres;
+    st->cover = cover;
     Scratch& S = st->S;
     float* dVerts; int32_t* dTris; float* dSpheres;
     float4 *primLo, *primHi;
@@ -715,7 +729,7 @@ int DeviceWideBuilder::topology(const float* verts, size_t nVerts, const int32_t
     const uint32_t initBounds[8] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u };
     YART_HIP(hipMemcpyAsync(dBounds, initBounds, sizeof initBounds, hipMemcpyHostToDevice, nullptr));
     hipLaunchKernelGGL(primBoxes, dim3(blocks(nP)), dim3(256), 0, nullptr, dVerts, dTris, (uint32_t)nTris, dSpheres, (uint32_t)nSpheres,
-                       (uint32_t)nVerts, primLo, primHi, dBounds);
+                       (uint32_t)nVerts, cover, primLo, primHi, dBounds);
     YART_HIP(hipGetLastError());
 
     // Morton codes, sorted
@@ -801,6 +815,13 @@ int DeviceWideBuilder::topology(const float* verts, size_t nVerts, const int32_t
     for (uint32_t lv = levels; lv-- > 0;)
         hipLaunchKernelGGL(fitLevel, dim3(blocks(nInternal)), dim3(256), 0, nullptr, left, right, (uint32_t)nInternal, depth, lv, nodeLo, nodeHi, plan);
     YART_HIP(hipGetLastError());
+    {
+        float4 rl, rh;
+        YART_HIP(hipMemcpy(&rl, nodeLo, sizeof rl, hipMemcpyDeviceToHost));
+        YART_HIP(hipMemcpy(&rh, nodeHi, sizeof rh, hipMemcpyDeviceToHost));
+        st->rootLo[0] = rl.x; st->rootLo[1] = rl.y; st->rootLo[2] = rl.z;
+        st->rootHi[0] = rh.x; st->rootHi[1] = rh.y; st->rootHi[2] = rh.z;
+    }
 
     // wide nodes, top-down
     WideNode* wide;
@@ -891,7 +912,8 @@ int DeviceWideBuilder::finish(const void* dTriAccel, const uint32_t* slotOfInput
         hipLaunchKernelGGL(packAssign, dim3(blocks(nNodes)), dim3(256), 0, nullptr, st->wide, nNodes, block, unitOf, leafUnit);
         hipLaunchKernelGGL(packNodes, dim3(blocks(nNodes)), dim3(256), 0, nullptr, st->wide, nNodes, block, unitOf, static_cast<uint4*>(units));
         hipLaunchKernelGGL(leafRows, dim3(blocks(st->n)), dim3(256), 0, nullptr, st->sortedIds, (uint32_t)st->n, (uint32_t)st->nTris, dSlot,
-                           static_cast<const float4*>(dTriAccel), reinterpret_cast<const float4*>(st->dSpheres), leafUnit, static_cast<float4*>(units));
+                           static_cast<const float4*>(dTriAccel), reinterpret_cast<const float4*>(st->dSpheres), st->dVerts, st->dTris, st->cover,
+                           leafUnit, static_cast<float4*>(units));
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -902,6 +924,8 @@ int DeviceWideBuilder::finish(const void* dTriAccel, const uint32_t* slotOfInput
     }
     out.units = units; out.numUnits = numUnits;
     out.numNodes = st->wideCount; out.numPrims = st->n; out.depth = st->wideDepth;
+    std::memcpy(out.rootLo, st->rootLo, 12);
+    std::memcpy(out.rootHi, st->rootHi, 12);
     out.msBuild = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - st->t0).count();
     out.msTopology = st->msTopology;
     out.msFinish = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tFinish0).count();
