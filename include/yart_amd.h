@@ -238,10 +238,12 @@ int yart_build_host(const float* verts, size_t n_verts,
  * boxes of the engine's own tree are guaranteed to hold everything the reference's primitive tests can
  * accept, rounding noise included (yart_amd/csrc/cover.h) -- the scene's bounds widened by 1/16 to 8 of its
  * diagonals.  Rays that start outside it are answered on the reference's tree (fix-up launches).
- * out[0..2] = lo, out[3..5] = hi, out[6] = D (longest distance from a covered origin to the scene),
- * out[7] = M (largest |coordinate|), out[8] = 2^-20 D^2, out[9] = bits of a uint32: 0 for an empty scene
- * (every origin covered). */
-int yart_scene_cover(const float* verts, size_t n_verts, const float* spheres, size_t n_spheres, float out[10]);
+ * out[0..2] = lo, out[3..5] = hi, out[6] = M (largest |coordinate| of a covered origin), out[7] = the farthest a
+ * triangle's error band reaches beyond the triangle's own box (the pruned walk of the reference's tree,
+ * YART_REFERENCE_TREE and the fix-up launches, culls that much later), out[8] unused, out[9] = bits of a uint32: 0
+ * for an empty scene (every origin covered). */
+int yart_scene_cover(const float* verts, size_t n_verts, const int32_t* tris, size_t n_tris,
+                     const float* spheres, size_t n_spheres, float out[10]);
 
 /* Host-only build of the engine's 4-wide tree (no HIP call; layout as yart_accel_get_wide).
  * Call with NULL array outputs to query n_nodes / n_prims, then again with arrays of that

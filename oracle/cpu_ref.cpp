@@ -381,22 +381,25 @@ bool sceneIntersectShadow(const Scene& sc, const Ray& r, Counters* c)
 constexpr float kCullSlack = 1.0f + 0x1p-18f;
 
 template <bool shadow>
-bool traverseEngine(const Scene& sc, const Ray& r, Hit& h, Counters* c)
+bool traverseEngine(const Scene& sc, const Ray& r, Hit& h, Counters* c, float padMax)
 {
     if (sc.nodes.empty()) return false;
+    // as yart_amd/csrc/traverse.hip: pruning allows for the triangles' error bands (cover.h: Cover::padMax)
+    float cullPad = padMax * std::fmax(std::fmax(std::fabs(1.0f / r.d[0]), std::fabs(1.0f / r.d[1])), std::fabs(1.0f / r.d[2]));
+    if (!(cullPad == cullPad)) cullPad = std::numeric_limits<float>::infinity();
     uint32_t stack[64];
     int sp = 0;
     bool hit = false;
     // the root sits in pair 0 next to an empty leaf: one 64-byte fetch = 2 records
     if (c) c->nodes += 2;
-    if (!slab(sc.nodes[0].b, r, shadow ? r.tmax : h.t * kCullSlack)) return false;
+    if (!slab(sc.nodes[0].b, r, shadow ? r.tmax : std::fma(h.t, kCullSlack, cullPad))) return false;
     uint32_t cur = 0;
     for (;;) {
         const Node& n = sc.nodes[cur];
         if (n.splitAxis != 3) {
             uint32_t l = cur + 1, rr = n.offset;
             if (c) c->nodes += 2;
-            float bound = shadow ? r.tmax : h.t * kCullSlack;      // as yart_amd/csrc/traverse.hip
+            float bound = shadow ? r.tmax : std::fma(h.t, kCullSlack, cullPad);      // as yart_amd/csrc/traverse.hip
             bool hl = slab(sc.nodes[l].b, r, bound);
             bool hr = slab(sc.nodes[rr].b, r, bound);
             uint32_t first = l, second = rr;
@@ -657,8 +660,9 @@ void orc_get_leaf_order(void* h, uint32_t* out)
 //         spheres still the reference's linear loop
 // counts (optional): 4 x uint32 per ray = triangle-tree node records fetched,
 //         triangle records tested, 0 (the oracle has no sphere tree), spheres tested
+// padMax: Cover::padMax of the scene (yart_scene_cover), mode 1 only
 void orc_intersect(void* h, const float* rays, size_t n, void* hitsOut, uint32_t* counts,
-                   int mode, int nthreads)
+                   int mode, int nthreads, float padMax)
 {
     const Scene& sc = *static_cast<Scene*>(h);
     Hit* out = static_cast<Hit*>(hitsOut);
@@ -677,7 +681,7 @@ void orc_intersect(void* h, const float* rays, size_t n, void* hitsOut, uint32_t
                     c.spheres++;
                     if (sphere(&sc.spheres[s * 4], r, hit.t)) { hit.prim = -(int32_t)s - 2; hit.u = hit.v = 0.0f; }
                 }
-                traverseEngine<false>(sc, r, hit, counts ? &c : nullptr);
+                traverseEngine<false>(sc, r, hit, counts ? &c : nullptr, padMax);
             }
             if (hit.prim == -1) { hit.u = 0.0f; hit.v = 0.0f; }
             out[i] = hit;
@@ -687,7 +691,7 @@ void orc_intersect(void* h, const float* rays, size_t n, void* hitsOut, uint32_t
 }
 
 void orc_intersect_shadow(void* h, const float* rays, size_t n, uint8_t* out, uint32_t* counts,
-                          int mode, int nthreads)
+                          int mode, int nthreads, float padMax)
 {
     const Scene& sc = *static_cast<Scene*>(h);
     parallelFor(n, nthreads, [&](size_t b, size_t e) {
@@ -705,7 +709,7 @@ void orc_intersect_shadow(void* h, const float* rays, size_t n, uint8_t* out, ui
                 for (size_t s = 0; s < nS && !occ; ++s) { c.spheres++; occ = sphere(&sc.spheres[s * 4], r, t); }
                 if (!occ) {
                     Hit hh; hh.t = r.tmax; hh.u = hh.v = 0.0f; hh.prim = -1;
-                    occ = traverseEngine<true>(sc, r, hh, counts ? &c : nullptr);
+                    occ = traverseEngine<true>(sc, r, hh, counts ? &c : nullptr, padMax);
                 }
             }
             out[i] = occ ? 1 : 0;

@@ -78,8 +78,8 @@ class Oracle:
         L.orc_get_nodes.argtypes = [c_vp, c_vp]
         L.orc_get_triaccel.argtypes = [c_vp, c_vp]
         L.orc_get_leaf_order.argtypes = [c_vp, c_vp]
-        L.orc_intersect.argtypes = [c_vp, c_vp, c_sz, c_vp, c_vp, ctypes.c_int, ctypes.c_int]
-        L.orc_intersect_shadow.argtypes = [c_vp, c_vp, c_sz, c_vp, c_vp, ctypes.c_int, ctypes.c_int]
+        L.orc_intersect.argtypes = [c_vp, c_vp, c_sz, c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_float]
+        L.orc_intersect_shadow.argtypes = [c_vp, c_vp, c_sz, c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_float]
         self.verts, self.tris, self.spheres = _scene_args(verts, tris, spheres)
         self.h = L.orc_scene_create(_p(self.verts), len(self.verts), _p(self.tris), len(self.tris),
                                     _p(self.spheres), len(self.spheres))
@@ -106,18 +106,19 @@ class Oracle:
         self.lib.orc_get_leaf_order(self.h, _p(out))
         return out
 
-    def intersect(self, rays, mode=0, counts=False, nthreads=8):
+    def intersect(self, rays, mode=0, counts=False, nthreads=8, pad_max=0.0):
+        """pad_max (mode 1): the scene's Cover::padMax, word 7 of yart_scene_cover -- how much later the pruned walk culls."""
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
         hits = np.zeros(len(rays), HIT_DTYPE)
         cnt = np.zeros((len(rays), 4), np.uint32) if counts else None
-        self.lib.orc_intersect(self.h, _p(rays), len(rays), _p(hits), _p(cnt), mode, nthreads)
+        self.lib.orc_intersect(self.h, _p(rays), len(rays), _p(hits), _p(cnt), mode, nthreads, float(pad_max))
         return (hits, cnt) if counts else hits
 
-    def intersect_shadow(self, rays, mode=0, counts=False, nthreads=8):
+    def intersect_shadow(self, rays, mode=0, counts=False, nthreads=8, pad_max=0.0):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
         occ = np.zeros(len(rays), np.uint8)
         cnt = np.zeros((len(rays), 4), np.uint32) if counts else None
-        self.lib.orc_intersect_shadow(self.h, _p(rays), len(rays), _p(occ), _p(cnt), mode, nthreads)
+        self.lib.orc_intersect_shadow(self.h, _p(rays), len(rays), _p(occ), _p(cnt), mode, nthreads, float(pad_max))
         return (occ, cnt) if counts else occ
 
 

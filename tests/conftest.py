@@ -47,7 +47,7 @@ def wide_walk(verts, tris, spheres, rays, any_hit=False, built=None, counts=Fals
     if built is None:
         built = api.build_wide_host(verts, tris, spheres)[:3]
     ref_nodes = api.build_host(verts, tris)[0]
-    cover = api.scene_cover(verts, spheres)
+    cover = api.scene_cover(verts, tris, spheres)
     rays = np.ascontiguousarray(rays, np.float32)
     got = orc.wide_intersect(built[0], built[1], built[2], rays, any_hit=any_hit, ref_nodes=ref_nodes, cover=cover, counts=counts)
     cnt = None
@@ -57,5 +57,5 @@ def wide_walk(verts, tris, spheres, rays, any_hit=False, built=None, counts=Fals
     if left.any():
         o = orc.Oracle(verts, tris, spheres)
         sub = np.ascontiguousarray(rays[left])
-        got[left] = o.intersect_shadow(sub, mode=1) if any_hit else o.intersect(sub, mode=1)
+        got[left] = o.intersect_shadow(sub, mode=1, pad_max=cover[7]) if any_hit else o.intersect(sub, mode=1, pad_max=cover[7])
     return (got, int(left.sum()), cnt) if counts else (got, int(left.sum()))

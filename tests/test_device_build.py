@@ -38,7 +38,7 @@ def test_device_built_tree_structure_and_parity(golden):
     assert_exact(exact, g["prim"], g["t"], g["u"], g["v"])
     # the oracle's walk of the dumped tree against the kernel, bit for bit
     rays = np.ascontiguousarray(g["rays"])
-    want = orc.wide_intersect(nodes, rows_a, rows_bc, rays, ref_nodes=acc.nodes(), cover=api.scene_cover(g["verts"], g["spheres"]))
+    want = orc.wide_intersect(nodes, rows_a, rows_bc, rays, ref_nodes=acc.nodes(), cover=api.scene_cover(g["verts"], g["tris"], g["spheres"]))
     got = api.hits_to_numpy(acc.intersect_closest(dev(rays), api.YART_RAYS_REGULAR))
     assert np.array_equal(got["prim"], want["prim"]) and np.array_equal(bits(got["t"]), bits(want["t"]))
     acc.close()

@@ -95,7 +95,8 @@ def test_fetch_counters_match_cpu_counting_oracle(golden, accel):
     the per-ray node / triangle fetch counts that define the algorithmic bytes."""
     from oracle import oracle as orc
     o = orc.Oracle(golden["verts"], golden["tris"], golden["spheres"])
-    _, want = o.intersect(golden["rays"], mode=1, counts=True)
+    pad_max = api.scene_cover(golden["verts"], golden["tris"], golden["spheres"])[7]
+    _, want = o.intersect(golden["rays"], mode=1, counts=True, pad_max=pad_max)
     rays = dev(golden["rays"])
     counts = torch.zeros((len(golden["rays"]), 4), dtype=torch.int32, device="cuda")
     hits = api.hits_to_numpy(accel.intersect_closest(rays, api.YART_REFERENCE_TREE, counts=counts))
@@ -104,7 +105,7 @@ def test_fetch_counters_match_cpu_counting_oracle(golden, accel):
     assert np.array_equal(got[:, 0], want[:, 0])           # triangle-tree node records fetched
     assert np.array_equal(got[:, 1], want[:, 1])           # triangle records tested
     assert (got[:, 3] <= want[:, 3]).all()                 # sphere tree never tests more than the linear loop
-    _, want_any = o.intersect_shadow(golden["shadow_rays"], mode=1, counts=True)
+    _, want_any = o.intersect_shadow(golden["shadow_rays"], mode=1, counts=True, pad_max=pad_max)
     counts.zero_()
     accel.intersect_any(dev(golden["shadow_rays"]), api.YART_REFERENCE_TREE, counts=counts)
     got_any = counts.cpu().numpy().astype(np.uint32)
@@ -234,7 +235,7 @@ def test_wide_tree_walk_on_cpu_agrees_with_kernel(golden, accel):
     from oracle import oracle as orc
     nodes, rows_a, rows_bc = accel.wide()
     assert nodes.shape[1] * 4 == 64 and len(rows_a) <= len(golden["tris"]) + len(golden["spheres"])
-    aux = dict(ref_nodes=accel.nodes(), cover=api.scene_cover(golden["verts"], golden["spheres"]))
+    aux = dict(ref_nodes=accel.nodes(), cover=api.scene_cover(golden["verts"], golden["tris"], golden["spheres"]))
     rays = np.ascontiguousarray(golden["rays"])
     want, want_cnt = orc.wide_intersect(nodes, rows_a, rows_bc, rays, counts=True, **aux)
     counts = torch.zeros((len(rays), 4), dtype=torch.int32, device="cuda")

@@ -203,15 +203,14 @@ def build_host(verts, tris):
     return nodes, ta
 
 
-def scene_cover(verts, spheres=None):
+def scene_cover(verts, tris, spheres=None):
     """-> float32[10]: the scene's cover (include/yart_amd.h: yart_scene_cover)."""
     L = lib()
-    verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
-    spheres = np.zeros((0, 4), np.float32) if spheres is None else np.ascontiguousarray(spheres, np.float32).reshape(-1, 4)
+    verts, tris, spheres = _scene_arrays(verts, tris, spheres)
     out = np.zeros(10, np.float32)
-    L.yart_scene_cover.argtypes = [_vp, _sz, _vp, _sz, _vp]
+    L.yart_scene_cover.argtypes = [_vp, _sz, _vp, _sz, _vp, _sz, _vp]
     L.yart_scene_cover.restype = ctypes.c_int
-    _check(L.yart_scene_cover(_p(verts), len(verts), _p(spheres), len(spheres), _p(out)))
+    _check(L.yart_scene_cover(_p(verts), len(verts), _p(tris), len(tris), _p(spheres), len(spheres), _p(out)))
     return out
 
 

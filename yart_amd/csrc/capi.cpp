@@ -460,6 +460,7 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
             a->dWideUnits = dw.units; a->wideUnits = dw.numUnits;
             std::memcpy(a->gridLo, dw.rootLo, 12);
             std::memcpy(a->gridHi, dw.rootHi, 12);
+            a->cover.padMax = dw.padMax;
             a->wideNodes = dw.numNodes; a->widePrims = dw.numPrims; a->wideDepth = dw.depth;
             a->deviceBytes += dw.numUnits * 16;
             a->hasWide = true;
@@ -476,11 +477,13 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
         a->wideUnits = packed.numUnits;
         std::memcpy(a->gridLo, wide.rootLo, 12);
         std::memcpy(a->gridHi, wide.rootHi, 12);
+        a->cover.padMax = wide.padMax;
         a->hasWide = (st == YART_OK);
         a->wideNodes = wide.nodes.size();
         a->widePrims = wide.rowsA.size() / 4;
         a->wideDepth = wide.depth;
     }
+    if (st == YART_OK && !a->hasWide) a->cover.padMax = yart::trianglePadMax(verts, tris, n_tris, a->cover);
     if (st == YART_OK && a->hasWide && n_tris) {
         // per triangle slot, where its leaf's box sits in the reference's pair array (traverse_wide.hip: near-edge hits, ties)
         hipError_t e = hipMalloc(&a->dLeafOfSlot, n_tris * 4);
@@ -830,10 +833,14 @@ int yart_build_host(const float* verts, size_t n_verts, const int32_t* tris, siz
     return YART_OK;
 }
 
-int yart_scene_cover(const float* verts, size_t n_verts, const float* spheres, size_t n_spheres, float out[10])
+int yart_scene_cover(const float* verts, size_t n_verts, const int32_t* tris, size_t n_tris, const float* spheres, size_t n_spheres, float out[10])
 {
-    if (!out || (n_verts && !verts) || (n_spheres && !spheres)) return fail(YART_ERR_INVALID_ARGUMENT, "yart_scene_cover: null argument");
-    const yart::Cover c = yart::sceneCover(verts, n_verts, spheres, n_spheres);
+    if (!out || (n_verts && !verts) || (n_spheres && !spheres) || (n_tris && !tris)) return fail(YART_ERR_INVALID_ARGUMENT, "yart_scene_cover: null argument");
+    for (size_t i = 0; i < n_tris; ++i)
+        for (int c = 0; c < 3; ++c)
+            if (tris[i * 5 + c] < 0 || static_cast<size_t>(tris[i * 5 + c]) >= n_verts) return fail(YART_ERR_INVALID_ARGUMENT, "yart_scene_cover: vertex index out of range");
+    yart::Cover c = yart::sceneCover(verts, n_verts, spheres, n_spheres);
+    c.padMax = yart::trianglePadMax(verts, tris, n_tris, c);
     static_assert(sizeof(yart::Cover) == 40, "ten words");
     std::memcpy(out, &c, sizeof c);
     return YART_OK;

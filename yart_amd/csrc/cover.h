@@ -38,7 +38,9 @@ namespace yart {
 struct Cover {
     float lo[3], hi[3];     // the ray origins the primitives' boxes are padded for
     float M;                // >= |coordinate| of any covered origin
-    float reserved[2];
+    float padMax;           // how far a triangle's error-band box (triBand) reaches beyond the triangle's own box, at most:
+                            // set by the builders; the pruned walk of the reference's tree culls that much later (traverse.hip)
+    float reserved;
     uint32_t valid;         // 0: nothing to bound (empty scene): every origin is covered
 };
 
@@ -77,6 +79,21 @@ YART_HD inline bool coverFinite(double x) { return x - x == 0.0; }
 YART_HD inline bool coverHolds(const Cover& c, float ox, float oy, float oz)
 {
     return !c.valid || (ox >= c.lo[0] && ox <= c.hi[0] && oy >= c.lo[1] && oy <= c.hi[1] && oz >= c.lo[2] && oz <= c.hi[2]);
+}
+
+// How far the band box [lo, hi] of triBand reaches beyond the bounding box of the triangle a, b, c.
+YART_HD inline float bandExcess(const float lo[3], const float hi[3], const float* a, const float* b, const float* c)
+{
+    float e = 0.0f;
+    for (int i = 0; i < 3; ++i) {
+        const float l = a[i] < b[i] ? (a[i] < c[i] ? a[i] : c[i]) : (b[i] < c[i] ? b[i] : c[i]);
+        const float h = a[i] > b[i] ? (a[i] > c[i] ? a[i] : c[i]) : (b[i] > c[i] ? b[i] : c[i]);
+        if (!(lo[i] <= hi[i])) return 0.0f;          // the empty box of a triangle that is never accepted
+        const float x = l - lo[i], y = hi[i] - h;
+        e = x > e ? x : e;
+        e = y > e ? y : e;
+    }
+    return e;
 }
 
 // The cover of a scene whose primitives lie (outliers aside, wide_build.cpp: sceneCover) in [slo, shi] and whose smallest

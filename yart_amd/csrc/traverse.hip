@@ -49,7 +49,8 @@ struct RayState {
     float ox, oy, oz, dx, dy, dz;
     float ix, iy, iz;                // 1.0f / dir, the division of include/bbox.h:36 hoisted
     float tmin, tmax;
-    float pad;                       // sphere tree: widening of every box for a ray that starts outside the scene's cover
+    float pad;                       // sphere tree: widening of every box for a ray that starts outside the scene's cover;
+                                     // triangle tree, pruned: how much later a node is culled (see startRay)
 };
 
 // include/bbox.h:30-50, operation for operation.  `tFar0` is ray.maxT in the
@@ -197,6 +198,13 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceParams P)
                 r.pad = 0x1.04p-10f * (fx + fy + fz);
             }
         }
+        if (PRIM == 0) {
+            // A triangle's test can accept a point its error band (cover.h) beyond the triangle's box, hence beyond the
+            // box of its leaf: up to padMax in space, padMax x the largest |1/d| along the ray.  Distance pruning
+            // allows for it; a scene of well-conditioned triangles has a padMax of a few ulps.
+            r.pad = P.cover.padMax * fmaxf(fmaxf(fabsf(r.ix), fabsf(r.iy)), fabsf(r.iz));
+            if (!(r.pad == r.pad)) r.pad = __builtin_inff();             // 0 x inf of an irregular ray: no pruning
+        }
         odd = !(finiteNonZero(r.ix) && finiteNonZero(r.iy) && finiteNonZero(r.iz) &&
                 fabsf(r.ox) < __builtin_inff() && fabsf(r.oy) < __builtin_inff() && fabsf(r.oz) < __builtin_inff() &&
                 r.tmin == r.tmin && r.tmax == r.tmax);
@@ -263,7 +271,7 @@ __global__ void __launch_bounds__(kBlock) traceKernel(TraceParams P)
                 const float4* p = P.pairs + (size_t)(cur & 0x1FFFFFFFu) * 4;
                 const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
                 const uint32_t axis = cur >> 29;
-                const float bound = (PRUNE && !ANY) ? tcur * kCullSlack : r.tmax;      // slack: see traverse_wide.hip
+                const float bound = (PRUNE && !ANY) ? __builtin_fmaf(tcur, kCullSlack, PRIM == 0 ? r.pad : 0.0f) : r.tmax;   // slack: see traverse_wide.hip
                 bool h0, h1;
                 const float pd = PRIM == 1 ? r.pad : 0.0f;      // x - 0 is x: the triangle tree's boxes are the reference's own
                 if (__ballot(odd) != 0) {            // rare: some lane's ray can produce NaN plane distances

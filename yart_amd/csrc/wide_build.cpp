@@ -321,6 +321,7 @@ private:
 };
 
 float bitsFloat(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+uint32_t floatBits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 
 // Collapse + emission.  The top of the tree is emitted by one thread into segment 0; every binary
 // subtree below `jobSpan` primitives becomes a job emitted by the pool into a segment of its own
@@ -663,7 +664,6 @@ void relayout(WideBvh& bvh, int mode)
     bvh.nodes.swap(out);
 }
 
-uint32_t floatBits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 constexpr uint32_t kStepMask = 0x7FE00000u;             // exponent + two mantissa bits
 
 } // namespace
@@ -901,6 +901,26 @@ Cover sceneCover(const float* verts, size_t nVerts, const float* spheres, size_t
     return makeCover(all.lo, all.hi, have, nSpheres, all.rMin < inf ? all.rMin : 0.0f);
 }
 
+float trianglePadMax(const float* verts, const int32_t* tris, size_t nTris, const Cover& cover)
+{
+    std::atomic<uint32_t> padMaxBits{ 0u };
+    parallelChunks(nTris, buildThreads(), size_t(1) << 16, [&](size_t b, size_t e) {
+        float chunkPad = 0.0f;
+        for (size_t i = b; i < e; ++i) {
+            const int32_t* t = tris + i * 5;
+            const float *va = verts + static_cast<size_t>(t[0]) * 3, *vb = verts + static_cast<size_t>(t[1]) * 3, *vc = verts + static_cast<size_t>(t[2]) * 3;
+            float rec[12], lo[3], hi[3];
+            uint32_t cls;
+            projectRecord(rec, va, vb, vc, t[4], t[3]);
+            triBand(rec, va, vb, vc, cover, lo, hi, cls);
+            chunkPad = std::max(chunkPad, bandExcess(lo, hi, va, vb, vc));
+        }
+        uint32_t bits = floatBits(chunkPad), seen = padMaxBits.load();
+        while (bits > seen && !padMaxBits.compare_exchange_weak(seen, bits)) { }
+    });
+    return bitsFloat(padMaxBits.load());
+}
+
 int buildWideBvh(const float* verts, size_t nVerts, const int32_t* tris, size_t nTris,
                  const TriangleBvh& tri, const float* spheres, size_t nSpheres,
                  int maxLeaf, const Cover& cover, WideBvh& out, std::string& err)
@@ -920,7 +940,9 @@ int buildWideBvh(const float* verts, size_t nVerts, const int32_t* tris, size_t 
     const size_t perTri = static_cast<size_t>(presplit);
     std::vector<BPrim> prims(nTris * perTri + nSpheres);
     std::vector<uint8_t> bandClass(nTris, 0);           // by leaf slot
+    std::atomic<uint32_t> padMaxBits{ 0u };             // non-negative floats order like their bits
     parallelChunks(nTris, buildThreads(), size_t(1) << 16, [&](size_t b, size_t e) {
+        float chunkPad = 0.0f;
         for (size_t i = b; i < e; ++i) {
             const int32_t* t = tris + i * 5;
             const float* vv[3] = { verts + static_cast<size_t>(t[0]) * 3, verts + static_cast<size_t>(t[1]) * 3,
@@ -931,6 +953,7 @@ int buildWideBvh(const float* verts, size_t nVerts, const int32_t* tris, size_t 
             const uint32_t slot = tri.slotOfInput[i];
             triBand(reinterpret_cast<const float*>(&tri.triaccel[slot]), vv[0], vv[1], vv[2], cover, whole.lo, whole.hi, cls);
             bandClass[slot] = static_cast<uint8_t>(cls);
+            chunkPad = std::max(chunkPad, bandExcess(whole.lo, whole.hi, vv[0], vv[1], vv[2]));
             whole.id = static_cast<uint32_t>(i);
             BPrim* out = &prims[i * perTri];
             int made = 0;
@@ -985,7 +1008,10 @@ int buildWideBvh(const float* verts, size_t nVerts, const int32_t* tris, size_t 
                 out[f].hi[0] = 0.0f;
             }
         }
+        uint32_t bits = floatBits(chunkPad), seen = padMaxBits.load();
+        while (bits > seen && !padMaxBits.compare_exchange_weak(seen, bits)) { }
     });
+    out.padMax = bitsFloat(padMaxBits.load());
     parallelChunks(nSpheres, buildThreads(), size_t(1) << 16, [&](size_t b, size_t e) {
         for (size_t i = b; i < e; ++i) {
             // the box of everything the fp64 sphere test (include/sphere.h:63-97) can accept from a covered ray: radius

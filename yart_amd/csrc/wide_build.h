@@ -67,6 +67,7 @@ struct WideBvh {
     int depth = 0;                      // wide levels (root = 1)
     size_t numLeaves = 0;
     float rootLo[3] = { 0, 0, 0 }, rootHi[3] = { 0, 0, 0 };     // bounds of all (padded) primitive boxes: every node's grid lies inside
+    float padMax = 0.0f;                // Cover::padMax of this scene (cover.h)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -118,6 +119,9 @@ int buildWideBvh(const float* verts, size_t nVerts, const int32_t* tris, size_t 
                  int maxLeaf, const Cover& cover, WideBvh& out, std::string& err);
 
 // The cover of a scene: bounds of its finite vertex coordinates and sphere extents, widened (cover.h: makeCover).
+// padMax is left 0: the builders fill it in (WideBvh::padMax, DeviceWide::padMax), or trianglePadMax for a scene that
+// gets no wide tree.  The triangles' vertex indices must have been checked.
 Cover sceneCover(const float* verts, size_t nVerts, const float* spheres, size_t nSpheres);
+float trianglePadMax(const float* verts, const int32_t* tris, size_t nTris, const Cover& cover);
 
 } // namespace yart

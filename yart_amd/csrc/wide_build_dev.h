@@ -16,6 +16,7 @@ struct DeviceWide {
     size_t numNodes = 0, numPrims = 0;
     int depth = 0;
     float rootLo[3] = { 0, 0, 0 }, rootHi[3] = { 0, 0, 0 };     // bounds of all (padded) primitive boxes
+    float padMax = 0.0f;            // Cover::padMax of this scene (cover.h)
     double msBuild = 0.0;           // wall time from the start of topology() to the end of finish()
     double msTopology = 0.0;        // of it: phase 1 (upload of the scene, sort, topology, fit, plan, wide nodes)
     double msFinish = 0.0;          // and phase 2 (leaf rows, exact-size arrays)

@@ -94,6 +94,8 @@ __global__ void __launch_bounds__(256) primBoxes(const float* __restrict__ verts
             uint32_t cls;
             projectRecord(rec, va, vb, vc, t[4], t[3]);
             triBand(rec, va, vb, vc, cover, l, h, cls);
+            const float ex = bandExcess(l, h, va, vb, vc);              // Cover::padMax
+            if (ex > 0.0f) atomicMax(bounds + 7, __float_as_uint(ex));
         }
     } else if (i < n) {
         const float* s = spheres + (size_t)(i - nTris) * 4;
@@ -688,6 +690,7 @@ struct DeviceWideBuilder::State {
     int32_t* dTris = nullptr;
     WideNode* wide = nullptr;
     Cover cover;
+    float padMax = 0.0f;
     float rootLo[3] = { 0, 0, 0 }, rootHi[3] = { 0, 0, 0 };     // bounds of the padded primitive boxes = of every node
     std::chrono::steady_clock::time_point t0;
     double msTopology = 0.0;
@@ -753,6 +756,7 @@ int DeviceWideBuilder::topology(const float* verts, size_t nVerts, const int32_t
     st->sortedIds = sortedIds;
     uint32_t hostBounds[8];
     YART_HIP(hipMemcpy(hostBounds, dBounds, sizeof hostBounds, hipMemcpyDeviceToHost));
+    std::memcpy(&st->padMax, &hostBounds[7], 4);
     const size_t n = hostBounds[6];                       // valid primitives: the first n sorted positions
     if (n < 2) { err = "device builder: fewer than two valid primitives"; return YART_ERR_INVALID_ARGUMENT; }
     st->n = n;
@@ -926,6 +930,7 @@ int DeviceWideBuilder::finish(const void* dTriAccel, const uint32_t* slotOfInput
     out.numNodes = st->wideCount; out.numPrims = st->n; out.depth = st->wideDepth;
     std::memcpy(out.rootLo, st->rootLo, 12);
     std::memcpy(out.rootHi, st->rootHi, 12);
+    out.padMax = st->padMax;
     out.msBuild = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - st->t0).count();
     out.msTopology = st->msTopology;
     out.msFinish = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tFinish0).count();
