@@ -277,13 +277,12 @@ def gather_check(rank, world, device):
     import torch
     import torch.distributed as dist
     from yart_amd import api, scenes
-    from oracle import diffuse_ref as dr          # camera_basis only: host arithmetic of Camera::Camera
     try:
         W, H = 640, 360
         v, t, s = scenes.architectural(40000, seed=2)
         acc = api.Accel(v, t, s, device=device)
         acc.set_surface_data(v, t, np.zeros_like(v), s)
-        cam = dr.camera_basis([-10.0, 5.0, 0.0], [1.0, -0.1, 0.05], W, H, 0.785398)
+        cam = api.camera_basis([-10.0, 5.0, 0.0], [1.0, -0.1, 0.05], W, H, 0.785398)
         job = (cam, W, H, 2, 4, [0.0, 9.0, 0.0], [60.0, 55.0, 50.0], [0.5, 0.5, 0.5])
         wf = api.Wavefront(acc, 1 << 16)
         ids = [api.Comm.unique_id() if rank == 0 else None]

@@ -234,6 +234,14 @@ int yart_build_host(const float* verts, size_t n_verts,
                     YartBvhNode* nodes_out, size_t* n_nodes,
                     YartTriAccel* triaccel_out);
 
+/* Replaces Camera::Camera (include/camera.h:9-22) for callers that hand a camera to yart_wavefront_render_diffuse or
+ * generate primary rays themselves: the four vectors a Camera holds, in fp32 with the reference's expressions --
+ * out[0..2] = position, out[3..5] = normal(dir) (src/rt.cpp:22-28 normalises before it constructs the camera,
+ * include/vector.h:165-167), out[6..8] = right_ = cross(direction, (0,1,0)) * (width * fov / height), out[9..11] = up_ =
+ * normal(cross(right_, direction)) * fov.  Camera::sample(x, y) (include/camera.h:24-31) then is
+ * normal(direction + right_ * (x / width - 0.5) + up_ * (y / height - 0.5)).  No HIP call. */
+int yart_camera_basis(const float pos[3], const float dir[3], int32_t width, int32_t height, float fov, float out[12]);
+
 /* The scene's COVER (no HIP call; no counterpart in the reference): the box of ray origins for which the
  * boxes of the engine's own tree are guaranteed to hold everything the reference's primitive tests can
  * accept, rounding noise included (yart_amd/csrc/cover.h) -- the scene's bounds widened by 1/16 to 8 of its

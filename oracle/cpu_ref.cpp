@@ -453,8 +453,23 @@ struct WideAux {
     const uint32_t* leafOfSlot = nullptr;       // triangle slot -> index of its leaf in refNodes
     float coverLo[3], coverHi[3];
     bool coverValid = false;
-    float gridLo[3], gridHi[3], gridExt[3];
+    float cullReach = 0.0f;                     // traverse.h: WideParams::cullReach (any bound of it serves)
 };
+
+// Which of two leaves (indices a != b into the reference's pre-order node array) the reference's walk reaches first
+// (src/bvhaccel.cpp:255-261): at their lowest common ancestor the left subtree iff dir[splitAxis] > 0.
+inline uint32_t tiedFirst(const Node* nodes, uint32_t a, uint32_t b, const Ray& r)
+{
+    const uint32_t lo = std::min(a, b), hi = std::max(a, b);
+    uint32_t i = 0;
+    while (nodes[i].splitAxis != 3) {
+        const uint32_t right = nodes[i].offset;
+        if (hi < right) i = i + 1;
+        else if (lo >= right) i = right;
+        else return r.d[nodes[i].splitAxis] > 0 ? lo : hi;
+    }
+    return lo;
+}
 constexpr int32_t kUnresolved = INT32_MIN;      // yart_amd/csrc/traverse.h kUnresolvedPrim; any-hit: 2
 
 inline float bandOfClass(uint32_t cls)          // cover.h
@@ -487,13 +502,9 @@ int traverseWide(const WideNodeRec* nodes, const float* rowsA, const float* rows
     if (!regularRay(r) || !covered) { out.t = 0.0f; out.u = out.v = 0.0f; out.prim = kUnresolved; return 2; }
     const float ix = 1.0f / r.d[0], iy = 1.0f / r.d[1], iz = 1.0f / r.d[2];
     const float inv[3] = { ix, iy, iz };
-    float cm = 0.0f;
-    for (int a = 0; a < 3; ++a) {
-        const float f = std::fmax(std::fabs(r.o[a] - aux.gridLo[a]), std::fabs(aux.gridHi[a] - r.o[a])) + aux.gridExt[a];
-        cm = std::fmax(cm, std::fabs(inv[a]) * f);
-    }
-    cm *= 0x1p-21f;
-    if (!(cm < inf)) { out.t = 0.0f; out.u = out.v = 0.0f; out.prim = kUnresolved; return 2; }
+    const float imax = std::fmax(std::fmax(std::fabs(ix), std::fabs(iy)), std::fabs(iz));
+    if (!(imax * aux.cullReach < inf)) { out.t = 0.0f; out.u = out.v = 0.0f; out.prim = kUnresolved; return 2; }
+    const float margin = 0x1p-21f * aux.cullReach;      // per unit of |1 / d|: entry planes are taken that much earlier, per axis
     float tTri = r.tmax, hu = 0.0f, hv = 0.0f, F = inf;
     int32_t primTri = -1, minS = -1, maxL = -1;
     uint32_t stack[128];
@@ -503,7 +514,7 @@ int traverseWide(const WideNodeRec* nodes, const float* rowsA, const float* rows
         if (!(cur & kLeaf)) {
             const WideNodeRec& n = nodes[cur];
             if (c) c->nodes += 4;
-            const float bound = std::fma(shadow ? r.tmax : fmin2(tTri, F), kCullSlack, cm);     // as traverse_wide.hip
+            const float bound = (shadow ? r.tmax : fmin2(tTri, F)) * kCullSlack;     // as traverse_wide.hip
             float tn[4];
             uint32_t rf[4];
             int nHit = 0;
@@ -513,7 +524,7 @@ int traverseWide(const WideNodeRec* nodes, const float* rowsA, const float* rows
                     const float A = (n.origin[a] - r.o[a]) * inv[a], B = n.scale[a] * inv[a];
                     const bool neg = inv[a] < 0.0f;
                     const float qn = (float)(neg ? n.qhi[a][ch] : n.qlo[a][ch]), qf = (float)(neg ? n.qlo[a][ch] : n.qhi[a][ch]);
-                    tNear = std::fmax(tNear, std::fma(qn, B, A));
+                    tNear = std::fmax(tNear, std::fma(qn, B, std::fma(std::fabs(inv[a]), -margin, A)));
                     tFar = std::fmin(tFar, std::fma(qf, B, A));
                 }
                 const bool h = !(tFar < tNear) && tNear < inf && n.ref[ch] != kNone;     // as traverse_wide.hip slab4 + its +inf marker
@@ -555,11 +566,13 @@ int traverseWide(const WideNodeRec* nodes, const float* rowsA, const float* rows
                         tTri = t; hu = u; hv = v; primTri = slot;
                     } else if (!shadow && primTri >= 0 && slot != primTri) {
                         // an exact-t tie with the triangle held: inside one leaf of the reference's tree the lower slot
-                        // wins; across two of its leaves its visiting order decides (see traverse_wide.hip)
+                        // wins; across two of its leaves the one its walk reaches first (see traverse_wide.hip)
                         float t2 = std::nextafter(tTri, inf);
                         if (wald(ta, r, t2, u, v) && t2 == tTri && counts(u, v)) {
-                            if (aux.refNodes && aux.leafOfSlot[slot] != aux.leafOfSlot[primTri]) { out.t = 0.0f; out.u = out.v = 0.0f; out.prim = kUnresolved; return 2; }
-                            if (slot < primTri) { hu = u; hv = v; primTri = slot; }
+                            bool first = slot < primTri;
+                            if (aux.refNodes && aux.leafOfSlot[slot] != aux.leafOfSlot[primTri])
+                                first = tiedFirst(aux.refNodes, aux.leafOfSlot[slot], aux.leafOfSlot[primTri], r) == aux.leafOfSlot[slot];
+                            if (first) { hu = u; hv = v; primTri = slot; }
                         }
                     }
                 } else {
@@ -752,20 +765,23 @@ void orc_wide_intersect(const void* nodes, const float* rowsA, const float* rows
         for (int a = 0; a < 3; ++a) { aux.coverLo[a] = cover[a]; aux.coverHi[a] = cover[3 + a]; }
     }
     {
-        // bounds of the root's child boxes: every grid of the tree lies inside (the kernel takes the builder's figure;
+        // bounds of the root's child boxes: every grid of the tree lies inside (the kernel takes the builders' figure;
         // the margin only has to be wide enough, the result does not depend on it)
         const float inf = std::numeric_limits<float>::infinity();
-        for (int a = 0; a < 3; ++a) { aux.gridLo[a] = inf; aux.gridHi[a] = -inf; }
+        float gridLo[3], gridHi[3];
+        for (int a = 0; a < 3; ++a) { gridLo[a] = inf; gridHi[a] = -inf; }
         for (int ch = 0; ch < 4; ++ch) {
             if (nd[0].ref[ch] == 0xFFFFFFFFu) continue;
             for (int a = 0; a < 3; ++a) {
-                aux.gridLo[a] = std::fmin(aux.gridLo[a], nd[0].origin[a] + nd[0].qlo[a][ch] * nd[0].scale[a]);
-                aux.gridHi[a] = std::fmax(aux.gridHi[a], nd[0].origin[a] + nd[0].qhi[a][ch] * nd[0].scale[a]);
+                gridLo[a] = std::fmin(gridLo[a], nd[0].origin[a] + nd[0].qlo[a][ch] * nd[0].scale[a]);
+                gridHi[a] = std::fmax(gridHi[a], nd[0].origin[a] + nd[0].qhi[a][ch] * nd[0].scale[a]);
             }
         }
         for (int a = 0; a < 3; ++a) {
-            if (!(aux.gridLo[a] <= aux.gridHi[a])) aux.gridLo[a] = aux.gridHi[a] = 0.0f;
-            aux.gridExt[a] = 1.25f * (aux.gridHi[a] - aux.gridLo[a]);
+            if (!(gridLo[a] <= gridHi[a])) gridLo[a] = gridHi[a] = 0.0f;
+            const float lo = aux.coverValid ? std::fmin(aux.coverLo[a], gridLo[a]) : gridLo[a];
+            const float hi = aux.coverValid ? std::fmax(aux.coverHi[a], gridHi[a]) : gridHi[a];
+            aux.cullReach = std::fmax(aux.cullReach, (hi - lo) + 1.25f * (gridHi[a] - gridLo[a]));
         }
     }
     parallelFor(n, nthreads, [&](size_t b, size_t e) {

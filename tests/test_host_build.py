@@ -98,3 +98,18 @@ def test_size_limits_are_errors_not_crashes():
     assert L.yart_build_wide_host(None, 0, None, 0, sph.ctypes.data_as(vp), 1 << 30, 1, None, ctypes.byref(nn),
                                   None, None, ctypes.byref(npr), ctypes.byref(depth)) == 1
     assert b"2^30" in L.yart_last_error()
+
+
+def test_camera_basis_is_the_reference_camera():
+    """yart_camera_basis (Camera::Camera, include/camera.h:9-22, after rt.cpp's normal(dir)) against the oracle's fp32
+    restatement, bit for bit; the product no longer borrows the checker's."""
+    from oracle import diffuse_ref as dr
+    for pos, d, w, h, fov in (([50.0, 48.0, 220.0], [0.0, -0.042612, -1.0], 512, 512, 0.785398),
+                              ([-10.0, 5.0, 0.0], [1.0, -0.1, 0.05], 1920, 1080, 0.785398),
+                              ([0.3, -2.0, 7.5], [0.2, 0.7, -0.4], 333, 77, 1.1)):
+        got = api.camera_basis(pos, d, w, h, fov)
+        want = dr.camera_basis(pos, d, w, h, fov)
+        for a, b in zip(got, want):
+            assert np.array_equal(np.asarray(a, np.float32).view(np.uint32), np.asarray(b, np.float32).view(np.uint32))
+    L = api.lib()
+    assert L.yart_camera_basis(None, None, 4, 4, ctypes.c_float(1.0), None) == 1

@@ -12,12 +12,11 @@ pytestmark = pytest.mark.gpu
 
 
 def test_tile_major_render_gathers_to_the_unsharded_frame():
-    from oracle import diffuse_ref as dr      # camera_basis: host arithmetic of Camera::Camera only
     v, t, s = scenes.architectural(20000, seed=5)
     acc = api.Accel(v, t, s)
     acc.set_surface_data(v, t, np.zeros_like(v), s)
     W, H = 200, 120                           # not a multiple of the tile size: strips and a corner tile
-    cam = dr.camera_basis([-10.0, 5.0, 0.0], [1.0, -0.1, 0.05], W, H, 0.785398)
+    cam = api.camera_basis([-10.0, 5.0, 0.0], [1.0, -0.1, 0.05], W, H, 0.785398)
     args = (cam, W, H, 2, 4, [0.0, 9.0, 0.0], [60.0, 55.0, 50.0], [0.5, 0.5, 0.5])
     wf = api.Wavefront(acc, 1 << 14)
     whole, _, _ = wf.render_diffuse(*args, seed=3)

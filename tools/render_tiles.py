@@ -49,7 +49,6 @@ def main():
     import torch
     import torch.distributed as dist
     from yart_amd import api, scenes, shard
-    from oracle import diffuse_ref as dr
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -70,7 +69,7 @@ def main():
     acc = api.Accel(verts, tris, sph, device=device)
     acc.set_surface_data(verts, tris, np.zeros_like(verts), sph)
     build_s = time.time() - t0
-    cam = dr.camera_basis([-10.0, 5.0, 0.0], [1.0, -0.1, 0.05], W, H, 0.785398)
+    cam = api.camera_basis([-10.0, 5.0, 0.0], [1.0, -0.1, 0.05], W, H, 0.785398)
     wf = api.Wavefront(acc, args.slots)
     job = (cam, W, H, args.spp, args.depth, LIGHT, INTENSITY, ALBEDO)
 
@@ -104,7 +103,8 @@ def main():
     # ---- every rank: a seeded sample of its pixels against the CPU loop over the oracle
     oracle_ok, oracle_n, oracle_diff = True, 0, 0
     if args.verify and args.oracle_pixels > 0:
-        from oracle import oracle as orc
+        from oracle import oracle as orc              # --verify only: the checker
+        from oracle import diffuse_ref as dr
         o = orc.Oracle(verts, tris, sph)
         nrm = dr.Normals(o, verts, tris, sph)
         rng = np.random.RandomState(100 + rank)

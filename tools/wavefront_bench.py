@@ -28,7 +28,6 @@ def main():
     args = ap.parse_args()
     import torch
     from yart_amd import api, scenes
-    from oracle import diffuse_ref as dr           # camera_basis only (host arithmetic of Camera::Camera)
 
     if args.config == "c3":
         W, H, spp, tris = 1920, 1080, args.spp or 64, args.tris or 262144
@@ -42,7 +41,7 @@ def main():
     acc = api.Accel(v, t, s)
     acc.set_surface_data(v, t, np.zeros_like(v), s)
     t2 = time.time()
-    cam = dr.camera_basis([-10.0, 5.0, 0.0], [1.0, -0.1, 0.05], W, H, 0.785398)
+    cam = api.camera_basis([-10.0, 5.0, 0.0], [1.0, -0.1, 0.05], W, H, 0.785398)
     light, inten, alb = [0.0, 9.0, 0.0], [60.0, 55.0, 50.0], [0.5, 0.5, 0.5]
     out = {"config": label, "scene": {"tris": int(acc.num_triangles), "spheres": int(acc.num_spheres), "device_MB": round(acc.device_bytes / 1e6, 1),
                                       "generate_s": round(t1 - t0, 1), "build_upload_s": round(t2 - t1, 1)},

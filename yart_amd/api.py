@@ -39,7 +39,7 @@ EXPORTS = [
     "yart_accel_get_nodes", "yart_accel_get_triaccel", "yart_accel_depth",
     "yart_accel_device_bytes", "yart_build_host", "yart_status_string", "yart_last_error",
     "yart_accel_profile_enable", "yart_accel_profile_read",
-    "yart_scene_cover", "yart_build_wide_host", "yart_accel_num_wide_nodes", "yart_accel_num_wide_prims", "yart_accel_wide_depth", "yart_accel_get_wide", "yart_accel_wide_built_on_device", "yart_accel_ref_built_on_device",
+    "yart_scene_cover", "yart_camera_basis", "yart_build_wide_host", "yart_accel_num_wide_nodes", "yart_accel_num_wide_prims", "yart_accel_wide_depth", "yart_accel_get_wide", "yart_accel_wide_built_on_device", "yart_accel_ref_built_on_device",
     "yart_obj_load", "yart_obj_free", "yart_obj_num_meshes", "yart_obj_num_vertices", "yart_obj_num_triangles",
     "yart_obj_num_materials", "yart_obj_num_spheres", "yart_obj_get", "yart_obj_mesh_name", "yart_obj_material_name",
     "yart_film_tonemap", "yart_film_write_bmp",
@@ -201,6 +201,19 @@ def build_host(verts, tris):
     ta = np.zeros(len(tris), TRIACCEL_DTYPE)
     _check(L.yart_build_host(_p(verts), len(verts), _p(tris), len(tris), _p(nodes), ctypes.byref(n), _p(ta)))
     return nodes, ta
+
+
+def camera_basis(pos, direction, width, height, fov):
+    """Camera::Camera (include/camera.h:9-22) -> (pos, dir, right, up) as float32[3] each: what Wavefront.render_diffuse
+    takes as `cam` (include/yart_amd.h: yart_camera_basis)."""
+    L = lib()
+    L.yart_camera_basis.argtypes = [_vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp]
+    L.yart_camera_basis.restype = ctypes.c_int
+    p = np.ascontiguousarray(pos, np.float32).reshape(3)
+    d = np.ascontiguousarray(direction, np.float32).reshape(3)
+    out = np.zeros(12, np.float32)
+    _check(L.yart_camera_basis(_p(p), _p(d), int(width), int(height), float(fov), _p(out)))
+    return out[0:3].copy(), out[3:6].copy(), out[6:9].copy(), out[9:12].copy()
 
 
 def scene_cover(verts, tris, spheres=None):

@@ -33,6 +33,7 @@ struct YartAccel {
     float sceneLo[3], sceneHi[3];     // bounds of everything, for the sort key grid
     yart::Cover cover;                // the rays the primitives' boxes are padded for (cover.h)
     float gridLo[3] = { 0, 0, 0 }, gridHi[3] = { 0, 0, 0 };   // bounds of the wide tree's (padded) primitive boxes
+    float cullReach = 0.0f;           // traverse.h: WideParams::cullReach
     // device memory
     void* dTriPairs = nullptr;
     void* dTriAccel = nullptr;

@@ -5,6 +5,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -216,12 +217,11 @@ int runIntersect(YartAccel* a, const Launch& L, const CallScratch* given)
         W.deferFlag = W.workCounter + 1;
         W.deferList = slot0 + 256;                  // behind the four counter slots (accel.h: kCounterBlockBytes)
         W.deferCap = yart::kDeferCap;
-        W.refPairs = static_cast<const float4*>(a->dTriPairs);
+        W.refNodes = static_cast<const float4*>(a->dRefNodes);
         W.leafOfSlot = static_cast<const uint32_t*>(a->dLeafOfSlot);
         W.cover = a->cover;
-        std::memcpy(W.gridLo, a->gridLo, 12);
-        std::memcpy(W.gridHi, a->gridHi, 12);
-        for (int c = 0; c < 3; ++c) W.gridExt[c] = 1.25f * (a->gridHi[c] - a->gridLo[c]);
+        W.cullReach = a->cullReach;
+        W.cullMargin = 0x1p-21f * a->cullReach;
         W.refillMin = a->wideRefillMin; W.nodeMin = a->wideNodeMin; W.sphereMin = a->wideSphereMin; W.chunk = a->wideChunk; W.maxBlocksPerCU = a->wideBlocksPerCU; W.laneCap = a->wideLaneCap; W.hasSpheres = a->numSpheres > 0 ? 1u : 0u;
         {
             ScopedSpan span(a, 2, L.stream);
@@ -484,10 +484,24 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
         a->wideDepth = wide.depth;
     }
     if (st == YART_OK && !a->hasWide) a->cover.padMax = yart::trianglePadMax(verts, tris, n_tris, a->cover);
+    if (st == YART_OK && a->hasWide) {
+        // |A| + 255 |B| of the wide kernel's box test <= cullReach x the largest |1 / d| of a covered ray (traverse_wide.hip)
+        float reach = 0.0f;
+        for (int c = 0; c < 3; ++c) {
+            const float lo = a->cover.valid ? std::min(a->cover.lo[c], a->gridLo[c]) : a->gridLo[c];
+            const float hi = a->cover.valid ? std::max(a->cover.hi[c], a->gridHi[c]) : a->gridHi[c];
+            reach = std::max(reach, (hi - lo) + 1.25f * (a->gridHi[c] - a->gridLo[c]));
+        }
+        a->cullReach = reach == reach ? reach : std::numeric_limits<float>::infinity();
+    }
     if (st == YART_OK && a->hasWide && n_tris) {
-        // per triangle slot, where its leaf's box sits in the reference's pair array (traverse_wide.hip: near-edge hits, ties)
+        // the reference's flattened nodes on the device (a device-built accel has them already) and, per triangle slot,
+        // its leaf there (traverse_wide.hip: near-edge hits, ties)
+        if (!a->dRefNodes) st = upload(&a->dRefNodes, a->tri.nodes.data(), a->tri.nodes.size() * sizeof(YartBvhNode), a->deviceBytes);
+    }
+    if (st == YART_OK && a->hasWide && n_tris) {
         hipError_t e = hipMalloc(&a->dLeafOfSlot, n_tris * 4);
-        if (e == hipSuccess) e = yart::launchLeafOfSlot(a->dTriPairs, a->numTriPairs, static_cast<uint32_t*>(a->dLeafOfSlot), nullptr);
+        if (e == hipSuccess) e = yart::launchLeafOfSlot(a->dRefNodes, a->numNodes, static_cast<uint32_t*>(a->dLeafOfSlot), nullptr);
         if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
         if (e != hipSuccess) st = failHip(e, "leaf table of the reference tree");
         else a->deviceBytes += n_tris * 4;
@@ -830,6 +844,29 @@ int yart_build_host(const float* verts, size_t n_verts, const int32_t* tris, siz
     if (n_nodes) *n_nodes = bvh.nodes.size();
     if (nodes_out) std::memcpy(nodes_out, bvh.nodes.data(), bvh.nodes.size() * sizeof(YartBvhNode));
     if (triaccel_out) std::memcpy(triaccel_out, bvh.triaccel.data(), bvh.triaccel.size() * sizeof(YartTriAccel));
+    return YART_OK;
+}
+
+int yart_camera_basis(const float pos[3], const float dir[3], int32_t width, int32_t height, float fov, float out[12])
+{
+    if (!pos || !dir || !out || width <= 0 || height <= 0) return fail(YART_ERR_INVALID_ARGUMENT, "yart_camera_basis: null argument or empty film");
+    // normal(Vector3f): v * (1.0f / length()) (include/vector.h:136-167), as src/rt.cpp:22-28 passes the direction
+    const float len = std::sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+    const float inv = 1.0f / len;
+    const float d[3] = { dir[0] * inv, dir[1] * inv, dir[2] * inv };
+    // Camera::Camera (include/camera.h:9-22): right_ = cross(direction_, up) * (width * fov_ / height_), up = (0, 1, 0);
+    // up_ = normal(cross(right_, direction_)) * fov_
+    const float up[3] = { 0.0f, 1.0f, 0.0f };
+    const float k = static_cast<float>(width) * fov / static_cast<float>(height);
+    const float r[3] = { (d[1] * up[2] - d[2] * up[1]) * k, (d[2] * up[0] - d[0] * up[2]) * k, (d[0] * up[1] - d[1] * up[0]) * k };
+    const float c[3] = { r[1] * d[2] - r[2] * d[1], r[2] * d[0] - r[0] * d[2], r[0] * d[1] - r[1] * d[0] };
+    const float cinv = 1.0f / std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    for (int i = 0; i < 3; ++i) {
+        out[i] = pos[i];
+        out[3 + i] = d[i];
+        out[6 + i] = r[i];
+        out[9 + i] = c[i] * cinv * fov;
+    }
     return YART_OK;
 }
 

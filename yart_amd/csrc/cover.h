@@ -57,7 +57,7 @@ YART_HD inline double coverFar2(const Cover& c, const float plo[3], const float 
 }
 
 constexpr double kHalfUlp = 5.9604644775390625e-08;      // 2^-24, unit roundoff of fp32
-constexpr double kSphereNoise = 9.5367431640625e-07;     // 2^-20 >= 13 * 2^-24: see sphereReff
+constexpr double kSphereNoise = 9.5367431640625e-07;     // 2^-20 = 16 * 2^-24: see sphereReff2
 
 YART_HD inline float coverNextUp(float f)
 {
@@ -103,8 +103,9 @@ YART_HD inline float bandExcess(const float lo[3], const float hi[3], const floa
 inline Cover makeCover(const float slo[3], const float shi[3], bool haveBounds, size_t nSpheres, float rMin);
 
 // include/sphere.h:66-70.  With op = fl(c - o) and unit roundoff h = 2^-24: |fl(b) - b| <= 3h |op| so b*b is off by
-// <= 6h |op|^2, fl(|op|^2) by <= 3h |op|^2, a direction normalised in fp32 has | |d|^2 - 1 | <= 4h: the computed
-// determinant exceeds r^2 - (distance of the centre from the ray)^2 by at most 13h |op|^2 < 2^-20 |op|^2.
+// <= 6h |op|^2, fl(|op|^2) by <= 3h |op|^2, a direction normalised in fp32 (v / sqrt(fl(v.v)), include/vector.h) has
+// | |d|^2 - 1 | <= 7h: the computed determinant exceeds r^2 - (distance of the centre from the ray)^2 by at most
+// 16h |op|^2 = 2^-20 |op|^2.
 // |op| <= the distance from the centre to the far corner of the cover.
 YART_HD inline double sphereReff2(const float s[4], const Cover& c)
 {

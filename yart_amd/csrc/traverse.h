@@ -76,18 +76,20 @@ struct WideParams {
     uint32_t laneCap;           // lanes of a wave that take rays (0 or 64: all): small batches spread over more, emptier waves
     uint32_t maxBlocksPerCU;    // 0 = as many as fit (8)
     uint32_t chunk;             // rays a wave takes from its range counter at a time (multiple of 64)
-    const float4* refPairs;     // the reference's triangle tree (sibling pairs, bvh_build.h): the box of a triangle's leaf there
-    const uint32_t* leafOfSlot; // leaf slot -> position (in float4 units) of that leaf's record in refPairs
+    const float4* refNodes;     // the reference's flattened nodes (YartBvhNode, 2 x float4 each): the box of a triangle's leaf
+                                // there (near-edge check), its topology (which of two tied leaves its walk reaches first)
+    const uint32_t* leafOfSlot; // leaf slot -> index of its leaf in refNodes
     Cover cover;                // rays that start outside it are left to the fix-up launches (cover.h)
-    float gridLo[3], gridHi[3]; // bounds of the (padded) primitive boxes: every node's grid lies inside
-    float gridExt[3];           // 1.25 x their extent (a node's 255 steps can overshoot its box by the step's rounding)
+    float cullReach;            // max over the axes of (longest way from a covered origin to the far side of the tree's bounds
+                                // + 1.25 x their extent): |A| + 255 |B| of slab4 <= cullReach x the largest |1 / d|
+    float cullMargin;           // 2^-21 cullReach
 };
 
 hipError_t launchTraceWide(const WideParams& P, bool any, bool count, bool persistent, int numCUs,
                            hipStream_t stream);
 
-// leafOfSlot[slot] = 4 * pair + 2 * child for every triangle slot of every leaf record of `pairs` (float4 units).
-hipError_t launchLeafOfSlot(const void* pairs, size_t numPairs, uint32_t* leafOfSlot, hipStream_t stream);
+// leafOfSlot[slot] = index of the slot's leaf in `nodes` (YartBvhNode array in the reference's order).
+hipError_t launchLeafOfSlot(const void* nodes, size_t numNodes, uint32_t* leafOfSlot, hipStream_t stream);
 
 // prim: 0 = triangle tree, 1 = sphere tree.
 hipError_t launchTrace(const TraceParams& P, int prim, bool any, bool prune, bool count,

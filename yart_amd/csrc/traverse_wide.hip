@@ -19,8 +19,9 @@
 //   result     the triangle iff its t is strictly below the sphere's float t, else the sphere
 //              (include/scene.h:142-167: spheres first, triangles must be strictly closer)
 // Exact-t ties between two different triangles: the reference keeps the first one ITS traversal finds.  Inside one
-// of its leaves that is the lower slot, which this kernel can tell (leafOfSlot); a tie across two of its leaves depends
-// on its visiting order, so such a ray is handed to the fix-up launches, which walk the reference's tree in that order.
+// of its leaves that is the lower slot; across two of its leaves it is the leaf its walk reaches first -- at the lowest
+// common ancestor of the two leaves the child on the side the ray points to (src/bvhaccel.cpp:255-261) -- which this
+// kernel finds by descending the reference's own node array (tiedFirst below; rare, a few dependent loads).
 //
 // False positives of the reference's tests (cover.h): every primitive's box holds all its test can accept from a
 // covered ray, and a triangle hit within the triangle's error band of an edge counts only if the ray passes the box
@@ -28,8 +29,8 @@
 // reaches that test at all.
 //
 // Rays that are not regularRay() (traverse.h) or start outside the scene's cover are left to the fix-up launches on the
-// reference tree; so are the tied rays above.  Such a ray's output holds a marker (kUnresolvedPrim / kUnresolvedOcc)
-// until the fix-up launch overwrites it.
+// reference tree.  Such a ray's output holds a marker (kUnresolvedPrim / kUnresolvedOcc) until the fix-up launch
+// overwrites it.
 // Built with -ffp-contract=off: every tested expression rounds as the reference's C++ does.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -69,7 +70,6 @@ __device__ __forceinline__ float sel3(int i, float a, float b, float c)
 
 struct WRay {
     float ox, oy, oz, dx, dy, dz, ix, iy, iz, tmax;
-    float cm;           // cull margin: what the rounding of slab4's plane distances can amount to for this ray
 };
 
 // include/bbox.h:30-50 for a regular ray (no NaN plane distance, minT = 0): the reference's own slab arithmetic
@@ -94,7 +94,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // conservative), so this arithmetic is free to use fma; the primitive tests are what has to round
 // like the reference.  tn[c] = entry distance, returns hit flags in h[c].
 __device__ __forceinline__ void slab4(const float4& q0, const float4& q1, const float4& q2, const WRay& r,
-                                      float bound, float tn[4], bool h[4])
+                                      float bound, float margin, float tn[4], bool h[4])
 {
     const uint32_t steps = __float_as_uint(q0.w);
     const float sx = __uint_as_float(steps & kStepMask), sy = __uint_as_float((steps << 10) & kStepMask),
@@ -108,13 +108,22 @@ __device__ __forceinline__ void slab4(const float4& q0, const float4& q1, const 
     const uint32_t nx = negx ? hx : lx, fx = negx ? lx : hx;      // byte c = entry / exit plane of child c
     const uint32_t ny = negy ? hy : ly, fy = negy ? ly : hy;
     const uint32_t nz = negz ? hz : lz, fz = negz ? lz : hz;
+    // Entry planes are taken EARLIER by what the rounding of t = q B + A can amount to on that axis: A = (origin_node - o) / d
+    // and B = step / d carry up to 2^-22 (|A| + 255 |B|) <= 2^-22 cullReach |1 / d| (every node's grid lies inside the
+    // bounds of the tree, o inside the cover); margin = twice that per unit of |1 / d|.  So a box is never culled against a
+    // hit that lies behind its true entry: without this the result for a ray through an edge shared by two triangles
+    // depended on which of them a wave happened to find first.  Per axis, because a ray nearly parallel to an axis has a
+    // huge |1 / d| there, and that axis must not loosen the other two.
+    const float Axn = __builtin_fmaf(fabsf(r.ix), -margin, Ax), Ayn = __builtin_fmaf(fabsf(r.iy), -margin, Ay),
+                Azn = __builtin_fmaf(fabsf(r.iz), -margin, Az);
     const f32x2 ax = { Ax, Ax }, bx = { Bx, Bx }, ay = { Ay, Ay }, by = { By, By }, az = { Az, Az }, bz = { Bz, Bz };
+    const f32x2 axn = { Axn, Axn }, ayn = { Ayn, Ayn }, azn = { Azn, Azn };
 #define YART_PAIR(w, s) (f32x2){ (float)(((w) >> (s)) & 255u), (float)(((w) >> ((s) + 8)) & 255u) }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        const f32x2 tnx = __builtin_elementwise_fma(YART_PAIR(nx, 16 * p), bx, ax);
-        const f32x2 tny = __builtin_elementwise_fma(YART_PAIR(ny, 16 * p), by, ay);
-        const f32x2 tnz = __builtin_elementwise_fma(YART_PAIR(nz, 16 * p), bz, az);
+        const f32x2 tnx = __builtin_elementwise_fma(YART_PAIR(nx, 16 * p), bx, axn);
+        const f32x2 tny = __builtin_elementwise_fma(YART_PAIR(ny, 16 * p), by, ayn);
+        const f32x2 tnz = __builtin_elementwise_fma(YART_PAIR(nz, 16 * p), bz, azn);
         const f32x2 tfx = __builtin_elementwise_fma(YART_PAIR(fx, 16 * p), bx, ax);
         const f32x2 tfy = __builtin_elementwise_fma(YART_PAIR(fy, 16 * p), by, ay);
         const f32x2 tfz = __builtin_elementwise_fma(YART_PAIR(fz, 16 * p), bz, az);
@@ -130,6 +139,61 @@ __device__ __forceinline__ void slab4(const float4& q0, const float4& q1, const 
         }
     }
 #undef YART_PAIR
+}
+
+// Which of two leaves of the reference's tree (indices a != b into its flattened, pre-order node array: left child at
+// i + 1, right child at `offset`, src/bvhaccel.cpp:215-234) its walk reaches first for a ray of direction d: at their
+// lowest common ancestor the left subtree iff d[splitAxis] > 0 (src/bvhaccel.cpp:255-261).
+__device__ __forceinline__ uint32_t tiedFirst(const float4* __restrict__ refNodes, uint32_t a, uint32_t b, float dx, float dy, float dz)
+{
+    const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+    uint32_t i = 0;
+    for (int guard = 0; guard < 128; ++guard) {
+        const float4 w = refNodes[2 * (size_t)i + 1];              // bounds_max.y, .z, offset, num | axis
+        const uint32_t right = __float_as_uint(w.z);
+        const uint32_t axis = (__float_as_uint(w.w) >> 8) & 255u;
+        if (axis == 3u) break;                                      // a leaf: cannot happen for a != b
+        if (hi < right) { i = i + 1; continue; }
+        if (lo >= right) { i = right; continue; }
+        const float d = axis == 0u ? dx : (axis == 1u ? dy : dz);
+        return d > 0.0f ? lo : hi;                                  // lo lies in the left subtree, hi in the right one
+    }
+    return lo;
+}
+
+// The triangle of leaf row `leafRef` gave exactly the t of the triangle held (primTri).  It takes its place iff it passes
+// the whole test (include/triaccel.h:169-201 with the bound one ulp above, the near-edge check of the common path) and the
+// reference's walk meets it first: the lower slot inside one of its leaves, the leaf tiedFirst names across two.
+__device__ __forceinline__ void tieBreak(const WideParams& P, const WRay& r, uint32_t leafRef, float tTri, float& hu, float& hv, int32_t& primTri)
+{
+    const float4 A = P.units[leafRef >> 2];
+    const uint32_t kw = __float_as_uint(A.w);
+    const int k = (int)(kw & 3u);
+    const uint32_t slot = (kw & kPackSlotMask) >> 2;
+    const float dk = sel3(k, r.dx, r.dy, r.dz), du = sel3(k, r.dy, r.dz, r.dx), dv = sel3(k, r.dz, r.dx, r.dy);
+    const float ok = sel3(k, r.ox, r.oy, r.oz), ou = sel3(k, r.oy, r.oz, r.ox), ov = sel3(k, r.oz, r.ox, r.oy);
+    const float nd = 1.0f / (dk + A.x * du + A.y * dv);
+    const float t = (A.z - ok - A.x * ou - A.y * ov) * nd;
+    if (!(t == tTri && t > 0.0001f)) return;
+    const float4* ta = P.triaccel + (size_t)slot * 3;
+    const float4 B = ta[1], C = ta[2];
+    const float phu = ou + t * du;
+    const float phv = ov + t * dv;
+    const float lambda = phu * B.x + phv * B.y + B.z;
+    if (lambda < 0.0f) return;
+    const float mue = phu * C.x + phv * C.y + C.z;
+    if (mue < 0.0f) return;
+    if (lambda + mue > 1.0f) return;
+    const uint32_t mine = P.leafOfSlot[slot], held = P.leafOfSlot[primTri];
+    if ((kw >> kPackBandShift) && fminf(fminf(lambda, mue), 1.0f - (lambda + mue)) < bandOfClass(kw >> kPackBandShift)) {
+        const float4* lb = P.refNodes + 2 * (size_t)mine;
+        const float4 b0 = lb[0], b1 = lb[1];
+        if (!slabRef(b0, b1, r)) return;
+    }
+    const bool first = mine == held ? (int32_t)slot < primTri : tiedFirst(P.refNodes, mine, held, r.dx, r.dy, r.dz) == mine;
+    if (!first) return;
+    hv = lambda; hu = mue;
+    primTri = (int32_t)slot;
 }
 
 #define YART_CSWAP(i, j)                                                   \
@@ -153,7 +217,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
     const uint64_t laneBit = 1ull << lane;
 
     WRay r;
-    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = r.tmax = r.cm = 0.0f;
+    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = r.tmax = 0.0f;
     uint32_t cur = kIdle;
     uint32_t pend = kIdle;                         // a triangle leaf set aside while the lane keeps descending
     uint32_t pendS = kIdle;                        // a sphere leaf set aside likewise: the sphere test is double-precision code
@@ -218,18 +282,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
         r.ox = a.x; r.oy = a.y; r.oz = a.z;
         r.dx = b.x; r.dy = b.y; r.dz = b.z; r.tmax = b.w;
         r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
-        {
-            // slab4's plane distance t = q B + A, A = (origin_node - o) / d, B = step / d, carries up to 2^-22 (|A| + 255 |B|)
-            // of rounding; every node's grid lies inside [gridLo, gridHi], so per axis |A| + 255 |B| <= (distance of o from
-            // the far side of that box + 1.25 x its extent) / |d|.  Nodes are culled against the best hit plus twice that
-            // (once per ray, not per node: for a ray nearly parallel to an axis the margin is wide and it culls less).
-            const float fx = fmaxf(fabsf(r.ox - P.gridLo[0]), fabsf(P.gridHi[0] - r.ox)) + P.gridExt[0];
-            const float fy = fmaxf(fabsf(r.oy - P.gridLo[1]), fabsf(P.gridHi[1] - r.oy)) + P.gridExt[1];
-            const float fz = fmaxf(fabsf(r.oz - P.gridLo[2]), fabsf(P.gridHi[2] - r.oz)) + P.gridExt[2];
-            r.cm = 0x1p-21f * fmaxf(fmaxf(fabsf(r.ix) * fx, fabsf(r.iy) * fy), fabsf(r.iz) * fz);
-            // a product that overflows: so could A or 255 B, and slab4 would see infinite planes of the wrong sign
-            if (!(r.cm < __builtin_inff())) { deferRay(rayId); return; }
-        }
+        // slab4 would see infinite planes of the wrong sign if A = (origin_node - o) / d or 255 B overflowed
+        if (!(fmaxf(fmaxf(fabsf(r.ix), fabsf(r.iy)), fabsf(r.iz)) * P.cullReach < __builtin_inff())) { deferRay(rayId); return; }
         tTri = r.tmax; hu = 0.0f; hv = 0.0f; primTri = -1;
         F = __builtin_inff(); minS = -1; maxL = -1; occ = 0;
         cNodes = 0; cTri = 0; cSph = 0; cStage2 = 0;
@@ -312,14 +366,15 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
                 // latency starts earlier.  C4 4.77 -> 4.68 ms, s = 0.01 7.81 -> 7.50 ms; the level (1..3) does not
                 // matter, and lowering it for the primitive tests as well gives half of that back.
                 __builtin_amdgcn_s_setprio(0);
-                const float bound = __builtin_fmaf(ANY ? r.tmax : (SPH ? fminf(tTri, F) : tTri), kCullSlack, r.cm);
+                // culled against the best hit so far, a relative hair later (kCullSlack); slab4 allows for its own rounding
+                const float bound = (ANY ? r.tmax : (SPH ? fminf(tTri, F) : tTri)) * kCullSlack;
                 float tn[4];
                 uint32_t rf[4];
                 const uint32_t blk = __float_as_uint(q2.z), offs = __float_as_uint(q2.w);
                 rf[0] = blk + (offs & 255u); rf[1] = blk + ((offs >> 8) & 255u);
                 rf[2] = blk + ((offs >> 16) & 255u); rf[3] = blk + (offs >> 24);
                 bool h[4];
-                slab4(q0, q1, q2, r, bound, tn, h);
+                slab4(q0, q1, q2, r, bound, P.cullMargin, tn, h);
                 // an unused slot needs no test of its own: its box is inverted on every axis (qlo 255, qhi 0:
                 // wide_build.cpp clear()), so it exits before it enters
                 if (COUNT) cNodes += 4;
@@ -344,7 +399,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
         { const uint64_t pm = __ballot(pend != kIdle); if (pm) { ++stLeafSteps; stLeafLanes += __popcll(pm); } ++stIters; stLive += __popcll(__ballot(live));
           const uint64_t sm = __ballot(sphNow && pendS != kIdle); if (sm) { ++stSphSteps; stSphLanes += __popcll(sm); } }
 #endif
-        bool stop = false, unresolved = false;
+        bool stop = false;
+        uint32_t tieRow = kIdle;
         if (pend != kIdle) {
             const uint32_t leaf = pend;
             pend = kIdle;
@@ -364,9 +420,11 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
                     const float t = (A.z - ok - A.x * ou - A.y * ov) * nd;
                     const float bound = ANY ? r.tmax : (SPH ? fminf(tTri, F) : tTri);
                     const uint32_t slot = (kw & kPackSlotMask) >> 2;
-                    // an exact tie with the triangle held so far is looked at too (below)
-                    const bool tie = !ANY && t == tTri && primTri >= 0 && (int32_t)slot != primTri;
-                    if (!((bound > t || tie) && t > 0.0001f)) break;
+                    if (!(bound > t && t > 0.0001f)) {
+                        // an exact tie with the triangle held so far is looked at after the common path (below)
+                        if (!ANY && t == tTri && primTri >= 0 && (int32_t)slot != primTri) tieRow = leaf;
+                        break;
+                    }
                     // second stage: rows b and c of the reference's TriAccel record of this slot
                     const float4* ta = P.triaccel + (size_t)slot * 3;
                     const float4 B = ta[1], C = ta[2];
@@ -383,25 +441,23 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
                     // reference's tree: the reference finds this hit only if the ray passes that box.
                     if (kw >> kPackBandShift) {
                         if (fminf(fminf(lambda, mue), 1.0f - (lambda + mue)) < bandOfClass(kw >> kPackBandShift)) {
-                            const float4* lb = P.refPairs + P.leafOfSlot[slot];
+                            const float4* lb = P.refNodes + 2 * (size_t)P.leafOfSlot[slot];
                             const float4 b0 = lb[0], b1 = lb[1];
                             if (!slabRef(b0, b1, r)) break;
                         }
                     }
                     if (ANY) { occ = 1; stop = true; break; }
-                    if (tie) {
-                        // The reference keeps the FIRST triangle it finds at a given t (`info->t > t` is strict).  Two
-                        // triangles of one of its leaves are tested in slot order: the lower slot wins.  Across two of
-                        // its leaves its visiting order decides: left to the fix-up launches.
-                        if (P.leafOfSlot[slot] != P.leafOfSlot[primTri]) { unresolved = true; break; }
-                        if ((int32_t)slot > primTri) break;
-                    }
                     tTri = t; hv = lambda; hu = mue;       // include/triaccel.h:194-196
                     primTri = (int32_t)slot;
                 } while (false);
             }
         }
-        if (unresolved) { deferRay(rayId); live = false; cur = kIdle; sp = 0; pend = kIdle; pendS = kIdle; }
+        if (!ANY && __ballot(tieRow != kIdle) != 0) {
+            // Rare: a second triangle at bit-identical t.  The reference keeps the FIRST one its walk finds (`info->t > t`
+            // is strict, include/triaccel.h:181); so the held one stays unless this one passes the whole test and comes
+            // earlier in the reference's order.  The test is run again from the rows: this path costs the common one nothing.
+            if (tieRow != kIdle) tieBreak(P, r, tieRow, tTri, hu, hv, primTri);
+        }
         if (SPH && sphNow && pendS != kIdle && !stop) {
             const float4* row = P.units + (pendS >> 2);
             pendS = kIdle;
@@ -522,24 +578,24 @@ hipError_t launchW(const WideParams& P, bool persistent, int numCUs, hipStream_t
     return hipGetLastError();
 }
 
-// Where the record of a triangle's leaf sits in the reference's pair array (the near-edge check and the tie rule above).
-__global__ void __launch_bounds__(256) leafOfSlotKernel(const uint4* __restrict__ pairs, uint32_t numPairs, uint32_t* __restrict__ leafOfSlot)
+// The leaf of every triangle slot in the reference's flattened node array (the near-edge check and the tie rule above).
+__global__ void __launch_bounds__(256) leafOfSlotKernel(const uint4* __restrict__ nodes, uint32_t numNodes, uint32_t* __restrict__ leafOfSlot)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;          // one child record per thread
-    if (i >= numPairs * 2u) return;
-    const uint32_t ref = pairs[(size_t)i * 2 + 1].z;             // DevNodeRec::ref (bvh_build.h)
-    if (!(ref & kLeafBit)) return;
-    const uint32_t slot0 = (ref & 0x7FFFFFFFu) >> 3, cnt = ref & 7u;
-    for (uint32_t k = 0; k < cnt; ++k) leafOfSlot[slot0 + k] = i * 2u;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= numNodes) return;
+    const uint4 w = nodes[(size_t)i * 2 + 1];                    // YartBvhNode: bounds_max.y, .z, offset, num_triangles | split_axis << 8
+    if (((w.w >> 8) & 255u) != 3u) return;
+    const uint32_t cnt = w.w & 255u;
+    for (uint32_t k = 0; k < cnt; ++k) leafOfSlot[w.z + k] = i;
 }
 
 } // namespace
 
-hipError_t launchLeafOfSlot(const void* pairs, size_t numPairs, uint32_t* leafOfSlot, hipStream_t stream)
+hipError_t launchLeafOfSlot(const void* nodes, size_t numNodes, uint32_t* leafOfSlot, hipStream_t stream)
 {
-    if (numPairs == 0) return hipSuccess;
-    const uint32_t n = (uint32_t)numPairs * 2u;
-    hipLaunchKernelGGL(leafOfSlotKernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, static_cast<const uint4*>(pairs), (uint32_t)numPairs, leafOfSlot);
+    if (numNodes == 0) return hipSuccess;
+    const uint32_t n = (uint32_t)numNodes;
+    hipLaunchKernelGGL(leafOfSlotKernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, static_cast<const uint4*>(nodes), n, leafOfSlot);
     return hipGetLastError();
 }
 
