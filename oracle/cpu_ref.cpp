@@ -496,6 +496,10 @@ int traverseWide(const WideNodeRec* nodes, const float* rowsA, const float* rows
 {
     const uint32_t kNone = 0xFFFFFFFFu, kLeaf = 0x80000000u, kSph = 0x40000000u;
     const float inf = std::numeric_limits<float>::infinity();
+    if (!(r.tmax > 0.0001f) && r.tmax == r.tmax) {        // as traverse_wide.hip: nothing can be accepted
+        out.t = r.tmax; out.u = out.v = 0.0f; out.prim = -1;
+        return 0;
+    }
     bool covered = true;
     if (aux.coverValid)
         for (int a = 0; a < 3; ++a) covered = covered && r.o[a] >= aux.coverLo[a] && r.o[a] <= aux.coverHi[a];

@@ -7,8 +7,8 @@ San-Miguel-class stand-in scenes, per-iteration batch statistics and end-to-end 
     python tools/wavefront_bench.py --config c5 --spp 256
 
 Size-independent checks at full size: the frames of runs with another slot count and in pool mode are
-compared bit for bit (a path's result does not depend on slot, batch or iteration; what can still differ
-is a ray that meets two primitives at distances one ulp apart, DESIGN.md section 1: counted); every pixel finite.
+and without the coherence sort are compared bit for bit (a path's result does not depend on slot, batch, iteration or
+the order a wave finds its candidates in: DESIGN.md section 1, order independence); every pixel finite.
 The small-size check against the CPU loop over the oracle is tests/test_wavefront_dev.py."""
 import argparse, json, os, sys, time
 import numpy as np
@@ -48,8 +48,8 @@ def main():
            "slots": args.slots}
     wf = api.Wavefront(acc, args.slots)
 
-    def run(spp_, regenerate, wfx=wf):
-        rgb, st, iters = wfx.render_diffuse(cam, W, H, spp_, args.depth, light, inten, alb, seed=1, regenerate=regenerate)
+    def run(spp_, regenerate, wfx=wf, flags=api.YART_SORT_RAYS):
+        rgb, st, iters = wfx.render_diffuse(cam, W, H, spp_, args.depth, light, inten, alb, seed=1, regenerate=regenerate, flags=flags)
         return rgb, st, iters
 
     if args.check_spp > 0:
@@ -58,12 +58,14 @@ def main():
         wf2 = api.Wavefront(acc, max(1000, args.slots // 3 + 17))
         c, _, _ = run(args.check_spp, True, wf2)
         wf2.close()
+        d, _, _ = run(args.check_spp, True, flags=0)           # batches traced in slot order, no coherence sort
         diff = lambda x, y: int((x.view(torch.int32) != y.view(torch.int32)).any(1).sum().item())
         out["checks"] = {"spp": args.check_spp, "pixels": int(a.shape[0]),
                          "pixels_differing_regenerate_vs_pools": diff(a, b),
                          "pixels_differing_other_slot_count": diff(a, c),
+                         "pixels_differing_unsorted": diff(a, d),
                          "all_finite": bool(torch.isfinite(a).all().item()), "mean_rgb": [round(float(x), 5) for x in a.mean(0).tolist()]}
-        del a, b, c
+        del a, b, c, d
     for name, regen in (("regenerate", True), ("pools", False)):
         run(1, regen)                                         # warm-up
         rgb, st, iters = run(spp, regen)

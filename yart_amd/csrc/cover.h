@@ -98,8 +98,8 @@ YART_HD inline float bandExcess(const float lo[3], const float hi[3], const floa
 
 // The cover of a scene whose primitives lie (outliers aside, wide_build.cpp: sceneCover) in [slo, shi] and whose smallest
 // sphere radius is rMin (nSpheres == 0: none).  The margin around that box is as wide as it can be while the sphere boxes
-// stay within 5 % of the spheres' radii (2^-20 D^2 <= 0.1 rMin^2), between 1/16 and 8 diagonals; for triangles the bounds
-// enter the band linearly and the margin costs nothing.
+// stay within 5 % of the spheres' radii (2^-20 D^2 <= 0.1 rMin^2), between 1/16 of a diagonal and one diagonal; for
+// triangles the bounds enter the band linearly (a margin of eight diagonals cost the architectural scenes 4-7 %).
 inline Cover makeCover(const float slo[3], const float shi[3], bool haveBounds, size_t nSpheres, float rMin);
 
 // include/sphere.h:66-70.  With op = fl(c - o) and unit roundoff h = 2^-24: |fl(b) - b| <= 3h |op| so b*b is off by
@@ -284,7 +284,7 @@ inline Cover makeCover(const float slo[3], const float shi[3], bool haveBounds, 
         m = std::fmax(m, std::fmax(std::fabs((double)slo[a]), std::fabs((double)shi[a])));
     }
     const double diag = std::sqrt(diag2);
-    double E = 8.0 * diag;
+    double E = diag;
     if (nSpheres) {
         const double allow = 323.8 * (double)rMin;               // 2^-20 D^2 <= 0.1 r^2
         const double Es = (allow - diag) / 1.7320508075688772;

@@ -275,6 +275,15 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 
         rayId = P.perm ? P.perm[slot] : slot;
         const float4 a = P.rays[(size_t)rayId * 2 + 0];
         const float4 b = P.rays[(size_t)rayId * 2 + 1];
+        if (!(b.w > 0.0001f) && b.w == b.w) {
+            // maxT <= 1e-4: no test can accept (`info->t > t && t > 0.0001f`, include/triaccel.h:181; `t > eps && t <
+            // hitInfo->t`, include/sphere.h:78,87), whatever else the ray holds: a miss.  The wavefront driver's idle
+            // slots carry such rays (wavefront.hip: deadRay).
+            if (ANY) P.occluded[rayId] = 0;
+            else P.hits[rayId] = make_float4(b.w, 0.0f, 0.0f, __int_as_float(-1));
+            if (COUNT) { uint32_t* c = P.counts + (size_t)rayId * 4; c[0] = c[1] = c[2] = c[3] = 0; }
+            return;
+        }
         if (!regularRay(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w) || !coverHolds(P.cover, a.x, a.y, a.z)) {
             deferRay(rayId);
             return;
