@@ -63,7 +63,14 @@ def main():
     ap.add_argument("--reference-tree", action="store_true",
                     help="traverse the reference's binary tree (sphere pass + triangle pass) instead of the 4-wide tree")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget; 0 disables it")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default, what the driver runs): --rays per GPU, every rank its own batch; strong: ONE batch of "
+                         "--rays (default 2^26 then), ordered once by the coherence key, contiguous slices per rank (SURVEY 8e)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the s = 0.002 / 0.01 points of configs[3] (N = 1 only)")
     args = ap.parse_args()
+    strong = args.scaling == "strong"
+    if strong and "--rays" not in " ".join(sys.argv):
+        args.rays = 1 << 26
 
     import torch
     import torch.distributed as dist
@@ -89,10 +96,31 @@ def main():
 
     t0 = time.time()
     verts, tris, sph = scenes.random_soup(args.tris, args.spheres, s=args.s, seed=42)
-    rays = scenes.random_rays(args.rays, seed=7 + rank)
+    rays = scenes.random_rays(args.rays, seed=7 if strong else 7 + rank)
     t1 = time.time()
     acc = api.Accel(verts, tris, sph, device=device)
     t2 = time.time()
+    total_rays = args.rays * (1 if strong else world)
+    if strong:
+        # SURVEY 8e throughput mode: the batch every rank holds is ordered ONCE by the coherence key (Morton cell of the
+        # origin on a 128^3 grid over the scene + direction octant, as sort.hip) and cut into contiguous slices, so a rank's
+        # rays stay in one region of the scene; outside the timed region (the caller's batch arrives ordered).
+        d_all = torch.from_numpy(rays).cuda()
+        lo = torch.from_numpy(verts.min(0)).cuda()
+        hi = torch.from_numpy(verts.max(0)).cuda()
+        q = ((d_all[:, 0:3] - lo) / (hi - lo) * 128.0).clamp_(0, 127).to(torch.int64)
+        key = torch.zeros(args.rays, dtype=torch.int64, device="cuda")
+        for bit in range(7):
+            for ax in range(3):
+                key |= ((q[:, ax] >> bit) & 1) << (3 * bit + ax + 3)
+        key |= (d_all[:, 4] < 0).to(torch.int64) | ((d_all[:, 5] < 0).to(torch.int64) << 1) | ((d_all[:, 6] < 0).to(torch.int64) << 2)
+        order = torch.argsort(key, stable=True)
+        from yart_amd import shard
+        begin, end = shard.ray_slice(args.rays, rank, world)
+        rays = d_all[order[begin:end]].cpu().numpy()
+        del d_all, q, key, order
+        torch.cuda.empty_cache()
+        args.rays = len(rays)
     if rank == 0:
         log("scene: %d tris, %d spheres, %d nodes, depth %d, %.1f MB in HBM (gen %.1fs, build+upload %.1fs)"
             % (acc.num_triangles, acc.num_spheres, acc.num_nodes, acc.depth, acc.device_bytes / 1e6, t1 - t0, t2 - t1))
@@ -150,7 +178,7 @@ def main():
     hit_frac = float((a["prim"] != -1).mean())
     del plain, d_occ, counted_hits
 
-    value = world * args.rays * args.steps / elapsed / 1e6
+    value = total_rays * args.steps / elapsed / 1e6
     out = {
         "metric": "Mrays/sec (closest-hit, incoherent paths)",
         "value": round(value, 2),
@@ -160,13 +188,14 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32 (f64 sphere test)",
         "data": "synthetic",
         "config": {
-            "workload": "BASELINE configs[3]: random soup %d tris (s=%g) + %d spheres, %d uniformly random rays per GPU, "
-                        "closest-hit, tree=%s, sort=%s, launch=%s" % (args.tris, args.s, args.spheres, args.rays,
+            "workload": "BASELINE configs[3]: random soup %d tris (s=%g) + %d spheres, %d uniformly random rays %s, "
+                        "closest-hit, tree=%s, sort=%s, launch=%s" % (args.tris, args.s, args.spheres, total_rays if strong else args.rays,
+                                                             "in ONE batch cut into contiguous slices of the coherence order, one per GPU" if strong else "per GPU",
                                                              "reference binary (sphere pass + triangle pass)" if args.reference_tree
                                                              else "4-wide quantised, triangles+spheres",
                                                              "off" if args.no_sort else "morton+octant",
@@ -187,17 +216,20 @@ def main():
     algorithmic = bytes_tri / t_tri / 1e9 if t_tri > 0 else 0.0
     traffic = None
     traffic_source = None
+    traffic_stale = False
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     key = "%stris=%d,spheres=%d,rays=%d,s=%g" % ("" if wide else "reftree,", args.tris, args.spheres, args.rays, args.s)
     if os.path.exists(traffic_file):
         try:
             tr = json.load(open(traffic_file))
-            if key in tr:
+            if key in tr and not strong:
                 traffic = tr[key]["hbm_bytes_per_launch"]
                 traffic_source = tr[key].get("source")
+                # the figure belongs to the kernel it was measured on: another tree of sources, no fraction
+                traffic_stale = tr[key].get("kernel_fingerprint") != api.kernel_fingerprint()
         except Exception as exc:     # a malformed side file must not break the bench line
             log("traffic.json ignored: %r" % (exc,))
-    achieved = traffic / t_tri / 1e9 if (traffic and t_tri > 0) else None
+    achieved = traffic / t_tri / 1e9 if (traffic and t_tri > 0 and not traffic_stale) else None
     out["roofline"] = {
         "bound": "hbm",
         "kernel": ("traceWide<closest> (yart_amd/csrc/traverse_wide.hip)" if wide
@@ -208,6 +240,8 @@ def main():
         "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved is not None else None,
         "traffic": traffic,
         "traffic_source": traffic_source,
+        "traffic_stale": traffic_stale,
+        "kernel_fingerprint": api.kernel_fingerprint(),
         "kernel_ms": round(t_tri * 1e3, 3),
         "algorithmic_GBps": round(algorithmic, 1),
         "algorithmic_bytes_per_launch": int(bytes_tri),
@@ -251,6 +285,16 @@ def main():
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"], out["parity_gate"]["sample_vs_cpu"] = cpu_baseline(
             verts, tris, sph, rays, a, args.cpu_seconds)
+    # ---- the other two points of configs[3]'s sweep over the soup's edge scale, N = 1 only
+    if rank == 0 and world == 1 and not strong and not args.no_sweep and args.s == 0.005:
+        del d_rays, d_hits
+        acc.close()
+        torch.cuda.empty_cache()
+        out["sweep"] = [{"s": args.s, "Mrays_s": out["value"], "ms_per_step": out["ms_per_step"], "kernel_ms": out["roofline"]["kernel_ms"],
+                         "hit_fraction": out["config"]["hit_fraction"]}]
+        for s_other in (0.002, 0.01):
+            out["sweep"].append(sweep_point(args, s_other, rays, flags))
+        out["sweep"].sort(key=lambda r: r["s"])
     # ---- N > 1: the one exchange the path has (image mode), exercised once outside the timed region:
     # every rank renders its tiles of a small frame, yart_frame_gather collects them over RCCL, rank 0 compares
     # with its own unsharded render.  Guarded by a watchdog: a stuck collective must not cost the bench line.
@@ -266,9 +310,41 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if stuck:
-        os._exit(0)
+        os._exit(3)             # the line above is printed; a hung collective must not pass for a clean run
     if world > 1:
         dist.destroy_process_group()
+
+
+def sweep_point(args, s, rays, flags):
+    """One more point of configs[3]: the same rays through the soup of edge scale s; timed like the headline, with the
+    size-independent part of the parity gate."""
+    import torch
+    from yart_amd import api, scenes
+    verts, tris, sph = scenes.random_soup(args.tris, args.spheres, s=s, seed=42)
+    acc = api.Accel(verts, tris, sph)
+    d_rays = torch.from_numpy(rays).cuda()
+    d_hits = torch.empty((len(rays), 4), dtype=torch.float32, device="cuda")
+    for _ in range(args.warmup):
+        acc.intersect_closest(d_rays, flags, out=d_hits)
+    torch.cuda.synchronize()
+    acc.profile(True)
+    acc.profile_read()
+    tic = time.perf_counter()
+    for _ in range(args.steps):
+        acc.intersect_closest(d_rays, flags, out=d_hits)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - tic
+    prof = acc.profile_read()
+    acc.profile(False)
+    plain = acc.intersect_closest(d_rays, api.YART_STATIC_LAUNCH | (flags & api.YART_REFERENCE_TREE))
+    same = bool(torch.equal(plain.view(torch.int32)[:, [0, 3]], d_hits.view(torch.int32)[:, [0, 3]]))
+    hit = float((d_hits.view(torch.int32)[:, 3] != -1).float().mean().item())
+    acc.close()
+    del d_rays, d_hits, plain
+    torch.cuda.empty_cache()
+    return {"s": s, "Mrays_s": round(len(rays) * args.steps / elapsed / 1e6, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "kernel_ms": round(prof["ms_triangles"] / max(1, args.steps), 3), "hit_fraction": round(hit, 4),
+            "sorted_persistent_equals_unsorted_static": same}
 
 
 def gather_check(rank, world, device):
@@ -297,10 +373,18 @@ def gather_check(rank, world, device):
         dist.barrier()
         ms = (time.perf_counter() - t0) * 1e3
         res = {"ranks": world, "frame": "%dx%d" % (W, H), "gather_ms_incl_barrier": round(ms, 3)}
+        # the second exchange of SURVEY 8e: counters + a checksum summed over the ranks behind the C-ABI (ncclAllReduce)
+        sums = torch.tensor([pix.numel(), rank + 1, int(local.view(torch.int32).to(torch.int64).sum().item()) & 0xFFFFFFFF],
+                            dtype=torch.int64, device="cuda")
+        comm.allreduce_u64(sums)
+        torch.cuda.synchronize()
+        sums = sums.cpu().tolist()
+        res["allreduce_u64"] = {"pixels": sums[0], "pixels_ok": sums[0] == W * H, "ranks_ok": sums[1] == world * (world + 1) // 2}
         if rank == 0:
             full, _, _ = wf.render_diffuse(*job, seed=5)
             res["rccl_gathered_frame_equals_single_rank_render_bitwise"] = bool(
                 torch.equal(full.view(H, W, 3).view(torch.int32), frame.view(torch.int32)))
+            res["allreduce_u64"]["checksum_ok"] = (int(full.view(torch.int32).to(torch.int64).sum().item()) & 0xFFFFFFFF) == (sums[2] & 0xFFFFFFFF)
         comm.close()
         wf.close()
         acc.close()

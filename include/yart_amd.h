@@ -412,6 +412,14 @@ void yart_comm_destroy(YartComm* comm);
  * row-major, device; ignored on other ranks).  Asynchronous on `stream`; world == 1 is the local scatter. */
 int yart_frame_gather(YartComm* comm, const float* d_local_rgb, int32_t width, int32_t height, int32_t tile,
                       float* d_frame_rgb, void* stream);
+/* ONE gather may be in flight per communicator: rank 0's staging block and tile tables belong to the communicator, and a
+ * call on another stream, or with another frame shape, first waits for the earlier gather's stream.
+ *
+ * The second exchange SURVEY 8(e) names: ray / hit counters and a checksum summed over the ranks (the reference's
+ * counterpart is none -- its workers share one address space, src/scheduler.cpp:46-72).  d_values: n uint64 on the
+ * communicator's device, replaced on every rank by their sum over all ranks (ncclAllReduce, ncclSum).  world == 1 leaves
+ * them as they are.  Asynchronous on `stream`. */
+int yart_comm_allreduce_u64(YartComm* comm, uint64_t* d_values, size_t n, void* stream);
 
 /* ---- Scene ingestion -------------------------------------------------------------
  * Replaces Scene::loadFromObj(folder, file) (src/scene.cpp:159-298) and, beneath it, the bundled

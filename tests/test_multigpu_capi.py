@@ -35,6 +35,18 @@ def test_tile_major_render_gathers_to_the_unsharded_frame():
         part, _, _ = wf.render_diffuse(*args, seed=3, pixels=torch.from_numpy(pix.astype(np.int32)).cuda())
         frame3.view(-1, 3)[torch.from_numpy(pix.astype(np.int64)).cuda()] = part
     assert torch.equal(frame3.view(torch.int32), frame.view(torch.int32))
+    # the counters / checksum exchange: over one rank the sum is the value; two gathers in a row on different streams
+    # and frame shapes (the tables and the staging block are replaced: the second call waits for the first)
+    vals = torch.tensor([7, 2**40 + 5, 2**63 - 1], dtype=torch.int64, device="cuda")
+    assert comm.allreduce_u64(vals.clone()).tolist() == vals.tolist()
+    other = torch.cuda.Stream()
+    pix2 = torch.from_numpy(api.tiles_rank_pixels(W, H, 0, 1, tile=16).astype(np.int32)).cuda()
+    local2, _, _ = wf.render_diffuse(*args, seed=3, pixels=pix2)
+    torch.cuda.synchronize()
+    f1 = comm.gather_frame(local, W, H)
+    f2 = comm.gather_frame(local2, W, H, tile=16, stream=other)
+    torch.cuda.synchronize()
+    assert torch.equal(f1.view(torch.int32), frame.view(torch.int32)) and torch.equal(f2.view(torch.int32), frame.view(torch.int32))
     comm.close()
     wf.close()
     acc.close()

@@ -4,6 +4,8 @@ request counters calibrated by tools/calib_fetch.hip (exact on a known streaming
 the traversal's scattered 64-byte reads).  Also records FETCH_SIZE / WRITE_SIZE and the request split.
     python tools/make_traffic.py gpurun_out/<tag>_pmc.txt "<kernel substring>" "<traffic key>" [calib file] """
 import json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from yart_amd import api
 
 pmc, kernel, key = sys.argv[1], sys.argv[2], sys.argv[3]
 calib = sys.argv[4] if len(sys.argv) > 4 else None
@@ -23,6 +25,7 @@ if missing:
 rd = 32.0 * vals["TCC_EA0_RDREQ_DRAM_32B_sum"]
 wr = 32.0 * vals["TCC_EA0_WRREQ_WRITE_DRAM_32B_sum"]
 entry = {
+    "kernel_fingerprint": api.kernel_fingerprint(),     # bench.py ignores the entry once the kernel sources change
     "hbm_bytes_per_launch": int(rd + wr),
     "read_bytes": int(rd), "write_bytes": int(wr),
     "source": "%s, %s: 32 B x (TCC_EA0_RDREQ_DRAM_32B + TCC_EA0_WRREQ_WRITE_DRAM_32B), separate --pmc passes; "

@@ -46,7 +46,7 @@ EXPORTS = [
     "yart_accel_set_surface_data", "yart_surface_dev", "yart_surface",
     "yart_wavefront_create", "yart_wavefront_destroy", "yart_wavefront_render_diffuse",
     "yart_tiles_count", "yart_tiles_list", "yart_tiles_rank_pixels",
-    "yart_comm_unique_id", "yart_comm_create", "yart_comm_destroy", "yart_frame_gather",
+    "yart_comm_unique_id", "yart_comm_create", "yart_comm_destroy", "yart_frame_gather", "yart_comm_allreduce_u64",
     "yart_queue_create", "yart_queue_destroy", "yart_queue_rays", "yart_queue_hits", "yart_queue_surfaces",
     "yart_queue_occluded", "yart_queue_closest", "yart_queue_any",
 ]
@@ -163,6 +163,7 @@ def lib():
     L.yart_comm_destroy.argtypes = [_vp]
     L.yart_comm_destroy.restype = None
     L.yart_frame_gather.argtypes = [_vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp]
+    L.yart_comm_allreduce_u64.argtypes = [_vp, _vp, _sz, _vp]
     L.yart_film_tonemap.argtypes = [_vp, _sz, _vp]
     L.yart_film_write_bmp.argtypes = [ctypes.c_char_p, _vp, ctypes.c_int32, ctypes.c_int32]
     L.yart_status_string.argtypes = [ctypes.c_int]
@@ -214,6 +215,18 @@ def camera_basis(pos, direction, width, height, fov):
     out = np.zeros(12, np.float32)
     _check(L.yart_camera_basis(_p(p), _p(d), int(width), int(height), float(fov), _p(out)))
     return out[0:3].copy(), out[3:6].copy(), out[6:9].copy(), out[9:12].copy()
+
+
+def kernel_fingerprint():
+    """Short hash of the sources that decide what the dominant kernel fetches (the traversal kernel, the tree formats and
+    builders, the padding rules).  profiles/traffic.json stamps its PMC figures with it, bench.py refuses a figure whose
+    stamp is not this tree's (tools/make_traffic.py)."""
+    import hashlib
+    h = hashlib.sha1()
+    for name in ("traverse_wide.hip", "traverse.hip", "traverse.h", "wide_build.h", "wide_build.cpp", "wide_build_dev.hip", "cover.h", "sort.hip"):
+        with open(os.path.join(_HERE, "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def scene_cover(verts, tris, spheres=None):
@@ -398,6 +411,14 @@ class Accel:
         import torch
         rays = self._rays(rays)
         n = rays.shape[0]
+
+        def check_out(t, cols, dtype, what):
+            if not (t.is_cuda and t.device == rays.device and t.is_contiguous() and t.dtype == dtype and tuple(t.shape) == (n, cols)):
+                raise YartError("%s must be a contiguous [%d, %d] %s tensor on the rays' device" % (what, n, cols, dtype))
+        if out is not None:
+            check_out(out, 4, torch.float32, "out")
+        if counts is not None:
+            check_out(counts, 4, torch.int32, "counts")
         if noalloc:
             if out is None or counts is not None:
                 raise YartError("noalloc: pass `out`, no `counts`")
@@ -532,6 +553,17 @@ class Comm:
         _check(lib().yart_frame_gather(self._h, _vp(local_rgb.data_ptr()), width, height, tile,
                                        _vp(frame.data_ptr()) if frame is not None else None, _vp(stream.cuda_stream)))
         return frame
+
+    def allreduce_u64(self, values, stream=None):
+        """values: contiguous CUDA tensor of n 64-bit integers (torch.int64 holds the uint64 bit patterns), summed over
+        the ranks in place (yart_comm_allreduce_u64: ray / hit counters and a checksum)."""
+        import torch
+        if not (values.is_cuda and values.is_contiguous() and values.dtype in (torch.int64, torch.uint64)):
+            raise YartError("values must be a contiguous 64-bit integer CUDA tensor")
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        _check(lib().yart_comm_allreduce_u64(self._h, _vp(values.data_ptr()), values.numel(), _vp(stream.cuda_stream)))
+        return values
 
 
 class Wavefront:

@@ -86,7 +86,8 @@ struct ScopedSpan {
     hipStream_t stream;
     YartAccel::Span span;
     bool on;
-    ScopedSpan(YartAccel* accel, int kind, hipStream_t s) : a(accel), stream(s), on(accel->profile)
+    // timed = false: a call that must not allocate (the no-alloc entry point: events and the span list are allocations)
+    ScopedSpan(YartAccel* accel, int kind, hipStream_t s, bool timed = true) : a(accel), stream(s), on(accel->profile && timed)
     {
         span.kind = kind;
         if (!on) return;
@@ -181,7 +182,7 @@ int runIntersect(YartAccel* a, const Launch& L, const CallScratch* given)
     if (sorted) {
         hipError_t e;
         {
-            ScopedSpan span(a, 0, L.stream);
+            ScopedSpan span(a, 0, L.stream, !given);
             e = yart::sortRays(reinterpret_cast<const float4*>(L.rays), n, a->sceneLo, a->sceneHi, a->sortOctShift, a->sortGridBits,
                                &perm, sc.sortWs, sc.sortWsBytes, L.stream);
         }
@@ -224,7 +225,7 @@ int runIntersect(YartAccel* a, const Launch& L, const CallScratch* given)
         W.cullMargin = 0x1p-21f * a->cullReach;
         W.refillMin = a->wideRefillMin; W.nodeMin = a->wideNodeMin; W.sphereMin = a->wideSphereMin; W.chunk = a->wideChunk; W.maxBlocksPerCU = a->wideBlocksPerCU; W.laneCap = a->wideLaneCap; W.hasSpheres = a->numSpheres > 0 ? 1u : 0u;
         {
-            ScopedSpan span(a, 2, L.stream);
+            ScopedSpan span(a, 2, L.stream, !given);
             e = yart::launchTraceWide(W, L.any, L.count, persistent, a->numCUs, L.stream);
         }
         // rays the wide kernel does not take (irregular, outside the cover, tied across reference leaves) are answered on
@@ -244,7 +245,7 @@ int runIntersect(YartAccel* a, const Launch& L, const CallScratch* given)
         P.primIndex = static_cast<const uint32_t*>(a->dSphIndex);
         P.workCounter = slot1;
         P.chained = 0;
-        ScopedSpan span(a, 1, L.stream);
+        ScopedSpan span(a, 1, L.stream, !given);
         e = yart::launchTrace(P, 1, L.any, prune, L.count, persistent, a->numCUs, L.stream);
     }
     if (e == hipSuccess && !skipRefTree) {
@@ -253,10 +254,10 @@ int runIntersect(YartAccel* a, const Launch& L, const CallScratch* given)
         P.primIndex = nullptr;
         P.workCounter = slot2;
         P.chained = a->numSpheres > 0 ? 1u : 0u;
-        ScopedSpan span(a, fixupOnly ? 1 : 2, L.stream);
+        ScopedSpan span(a, fixupOnly ? 1 : 2, L.stream, !given);
         e = yart::launchTrace(P, 0, L.any, prune, L.count, persistent, a->numCUs, L.stream);
     }
-    if (a->profile) {
+    if (a->profile && !given) {
         std::lock_guard<std::mutex> lock(a->profileMutex);
         a->profiledCalls++;
     }
@@ -508,7 +509,11 @@ int yart_accel_create(const float* verts, size_t n_verts, const int32_t* tris, s
     }
     // this device's copy of the static scratch of yart_intersect_closest_noalloc_dev (looked up once per
     // device, with that device current)
-    if (st == YART_OK) st = yart::noallocScratchOfDevice(device, &a->noallocScratch, &a->noallocBytes);
+    // (a device the table does not reach, or a failed lookup, leaves it null: only the no-alloc call then fails)
+    if (st == YART_OK && yart::noallocScratchOfDevice(device, &a->noallocScratch, &a->noallocBytes) != YART_OK) {
+        a->noallocScratch = nullptr;
+        a->noallocBytes = 0;
+    }
     if (st != YART_OK) { yart_accel_destroy(a); return st; }
     // the device copy is authoritative from here on; the pair array is not needed on the host
     a->tri.pairs.clear();

@@ -73,6 +73,7 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -96,6 +97,7 @@ Rccl* rccl()
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
         r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
         r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
         r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
         r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
@@ -124,6 +126,8 @@ struct YartComm {
     void* tables = nullptr;
     size_t tablesBytes = 0;
     int32_t tabWidth = 0, tabHeight = 0, tabTile = 0;
+    hipStream_t lastStream = nullptr;   // the stream of the last gather: ONE gather may be in flight per communicator; its
+    bool used = false;                  // scatter kernels read `tables` and `staging`, which a later call may replace
     std::vector<size_t> tabRectOffset, tabFirstOffset, tabTiles;     // per rank: byte offsets into `tables`, tile counts
 };
 
@@ -226,7 +230,18 @@ int yart_frame_gather(YartComm* c, const float* d_local, int32_t width, int32_t 
 
     // rank 0: tile tables of this frame shape on the device (kept until the shape changes)
     hipError_t he = hipSuccess;
+    // An earlier gather's scatter kernels may still be reading the tables and the staging block (streams created
+    // non-blocking do not wait for the copies and frees below): wait for it before either is replaced.  One gather
+    // may be in flight per communicator; a caller that needs two at once creates two.
+    auto drainEarlier = [&]() -> hipError_t {
+        if (!c->used) return hipSuccess;
+        const hipError_t e = hipStreamSynchronize(c->lastStream);
+        c->used = false;
+        return e;
+    };
+    if (c->used && c->lastStream != stream && (he = drainEarlier()) != hipSuccess) return failStatus(YART_ERR_HIP, std::string("hipStreamSynchronize(earlier gather): ") + hipGetErrorString(he));
     if (c->tabWidth != width || c->tabHeight != height || c->tabTile != tile) {
+        if ((he = drainEarlier()) != hipSuccess) return failStatus(YART_ERR_HIP, std::string("hipStreamSynchronize(earlier gather): ") + hipGetErrorString(he));
         std::vector<char> host;
         c->tabRectOffset.assign(c->world, 0); c->tabFirstOffset.assign(c->world, 0); c->tabTiles.assign(c->world, 0);
         for (int32_t rk = 0; rk < c->world; ++rk) {
@@ -254,6 +269,7 @@ int yart_frame_gather(YartComm* c, const float* d_local, int32_t width, int32_t 
             if ((he = hipMalloc(&c->tables, host.size())) != hipSuccess) return failStatus(YART_ERR_OUT_OF_MEMORY, std::string("hipMalloc(tile tables): ") + hipGetErrorString(he));
             c->tablesBytes = host.size();
         }
+        c->tabWidth = c->tabHeight = c->tabTile = 0;           // not valid until the copy below has succeeded
         if ((he = hipMemcpy(c->tables, host.data(), host.size(), hipMemcpyHostToDevice)) != hipSuccess) return failStatus(YART_ERR_HIP, std::string("hipMemcpy(tile tables): ") + hipGetErrorString(he));
         c->tabWidth = width; c->tabHeight = height; c->tabTile = tile;
     }
@@ -265,11 +281,14 @@ int yart_frame_gather(YartComm* c, const float* d_local, int32_t width, int32_t 
         if (rk > 0) { offset[rk] = others; others += (count[rk] * 12 + 255) & ~size_t(255); }
     }
     if (others > c->stagingBytes) {
+        if ((he = drainEarlier()) != hipSuccess) return failStatus(YART_ERR_HIP, std::string("hipStreamSynchronize(earlier gather): ") + hipGetErrorString(he));
         (void)hipFree(c->staging);
         c->staging = nullptr; c->stagingBytes = 0;
         if ((he = hipMalloc(&c->staging, others)) != hipSuccess) return failStatus(YART_ERR_OUT_OF_MEMORY, std::string("hipMalloc(gather staging): ") + hipGetErrorString(he));
         c->stagingBytes = others;
     }
+    c->lastStream = stream;
+    c->used = true;
     if (c->world > 1) {
         ncclResult_t e = r->GroupStart();
         for (int32_t rk = 1; rk < c->world && e == ncclSuccess; ++rk)
@@ -288,6 +307,20 @@ int yart_frame_gather(YartComm* c, const float* d_local, int32_t width, int32_t 
         if ((he = hipGetLastError()) != hipSuccess) return failStatus(YART_ERR_HIP, std::string("scatterTiles: ") + hipGetErrorString(he));
     }
     return YART_OK;
+}
+
+int yart_comm_allreduce_u64(YartComm* c, uint64_t* d_values, size_t n, void* streamPtr)
+{
+    using namespace yart;
+    if (!c || (n && !d_values)) return failStatus(YART_ERR_INVALID_ARGUMENT, "yart_comm_allreduce_u64: null argument");
+    if (n == 0 || c->world == 1) return YART_OK;             // the sum over one rank is the value itself
+    Rccl* r = rccl();
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (hipSetDevice(c->device) != hipSuccess) return failStatus(YART_ERR_NO_DEVICE, "hipSetDevice failed");
+    const ncclResult_t e = r->AllReduce(d_values, d_values, n, ncclUint64, ncclSum, c->comm, static_cast<hipStream_t>(streamPtr));
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return e == ncclSuccess ? YART_OK : ncclFail(e, "ncclAllReduce");
 }
 
 } // extern "C"

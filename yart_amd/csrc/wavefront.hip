@@ -135,8 +135,11 @@ __global__ void __launch_bounds__(256) wfGenerate(WfBuffers B, DiffuseParams J, 
     if ((threadIdx.x & 63u) == 0) lds[threadIdx.x >> 6] = mine;
     __syncthreads();
     if (threadIdx.x == 0) {
+        // Nothing is reserved once the slab's paths are all handed out: the counter would otherwise grow by the free slots
+        // of every drain iteration and, with many slots and a deep path limit, wrap around 2^32 and hand paths out twice.
         const uint32_t total = lds[0] + lds[1] + lds[2] + lds[3];
-        lds[4] = total ? atomicAdd(B.counters + 0 * kCtr, total) : 0u;
+        const uint32_t seen = __hip_atomic_load(B.counters + 0 * kCtr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lds[4] = (total && seen < J.slabPaths) ? atomicAdd(B.counters + 0 * kCtr, total) : J.slabPaths;
     }
     __syncthreads();
     uint32_t next = lds[4];                                  // first path number of the chunk being handed out
