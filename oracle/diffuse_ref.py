@@ -154,6 +154,7 @@ def render(oracle, normals, cam, width, height, spp, max_depth, light_pos, light
             q = (f32(0.2126) * w[:, 0] + f32(0.7152) * w[:, 1]) + f32(0.0722) * w[:, 2]
             go = ~(rnd(key, dim + 3) > q) & (q > 0) & (bounce + 1 < max_depth)
             idx, rays, P, nl, w, key, q = idx[go], rays[go], P[go], nl[go], w[go], key[go], q[go]
+            dcur = rays[:, 4:7]
             if len(idx) == 0:
                 break
             w = (w / q[:, None]).astype(f32)
@@ -180,13 +181,19 @@ def render(oracle, normals, cam, width, height, spp, max_depth, light_pos, light
             sx = ny * fz - nz * fy
             sy = nz * fx - nx * fz
             sz = nx * fy - ny * fx
+            pdf_l = lz * INV_PI
+            woz = -((dcur[:, 0] * nx + dcur[:, 1] * ny) + dcur[:, 2] * nz)      # Lambertian::sample: wi on wo's side
+            lz = np.where(woz < 0, -lz, lz).astype(f32)
             dd = np.empty((len(idx), 3), f32)
             dd[:, 0] = (lx * sx + ly * fx) + lz * nx
             dd[:, 1] = (lx * sy + ly * fy) + lz * ny
             dd[:, 2] = (lx * sz + ly * fz) + lz * nz
-            go2 = lz != 0
+            cos_w = np.abs((dd[:, 0] * nl[:, 0] + dd[:, 1] * nl[:, 1]) + dd[:, 2] * nl[:, 2])
+            with np.errstate(divide="ignore", invalid="ignore"):
+                for c in range(3):
+                    w[:, c] = ((w[:, c] * (alb[c] * INV_PI)) * cos_w) / pdf_l
+            go2 = ~(np.abs(lz) < EPS)
             idx, P, w, key, dd = idx[go2], P[go2], w[go2], key[go2], dd[go2]
-            w = (w * alb[None]).astype(f32)
             rays = np.zeros((len(idx), 8), f32)
             rays[:, 0:3] = P + dd * EPS
             rays[:, 4:7] = dd

@@ -337,3 +337,27 @@ def reference_trace_cornell(width, height, pixels, mode=0, nthreads=8, engine=No
             raise RuntimeError("engine call failed inside the wavefront driver")
         return rgb, dict(rays=int(rc), closest_batches=int(ncl.value), largest_batch=int(nsh.value))
     return rgb
+
+
+def reference_trace_diffuse(verts, tris, spheres, albedo, light_pos, light_intensity, cam_pos, cam_dir, fov, width, height,
+                            pixels=None, nthreads=8):
+    """The real reference's trace() (4096 spp, <= 10 bounces) with its own Lambertian / PointLight on the given scene
+    (ref_shim.cpp: ref_trace_diffuse) -> (rgb float32 [n, 3] in pixel-list order, vertex normals the reference's
+    TriangleMesh constructor generated, float32 [nVerts, 3])."""
+    L = ctypes.CDLL(REF_SO)
+    verts, tris, spheres = _scene_args(verts, tris, spheres)
+    if pixels is None:
+        pixels = np.arange(width * height)
+    xy = np.ascontiguousarray(np.stack([np.asarray(pixels) % width, np.asarray(pixels) // width], 1).astype(np.int32))
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    rgb = np.zeros((len(xy), 3), np.float32)
+    normals = np.zeros((len(verts), 3), np.float32)
+    L.ref_trace_diffuse.argtypes = [c_vp, c_sz, c_vp, c_sz, c_vp, c_sz, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_float, ctypes.c_int,
+                                    ctypes.c_int, c_vp, c_sz, ctypes.c_int, c_vp, c_vp]
+    L.ref_trace_diffuse.restype = ctypes.c_int
+    a, lp, li, cp, cd = f(albedo), f(light_pos), f(light_intensity), f(cam_pos), f(cam_dir)
+    st = L.ref_trace_diffuse(_p(verts), len(verts), _p(tris), len(tris), _p(spheres), len(spheres), _p(a), _p(lp), _p(li),
+                             _p(cp), _p(cd), float(fov), int(width), int(height), _p(xy), len(xy), nthreads, _p(rgb), _p(normals))
+    if st != 0:
+        raise ValueError("ref_trace_diffuse: bad scene")
+    return rgb, normals

@@ -524,6 +524,64 @@ long ref_trace_cornell(int width, int height, const int32_t* pixels, size_t nPix
 
 void ref_free(void* p) { std::free(p); }
 
+// The reference's OWN integrator on a caller's scene: trace() (src/renderer.cpp:29-136, 4096 samples per pixel, <= 10
+// bounces, Rng(y * width + x)) with the reference's Lambertian (src/bsdf.cpp:79-95) on every mesh and sphere and one
+// PointLight (include/light.h:33-58), camera as src/rt.cpp:22-28 builds it (normal(dir)).  The fixture the DEVICE
+// integrator (yart_amd/csrc/wavefront.hip) is pinned to: tests/golden/g6_trace_diffuse.npz.
+//   pixels: x, y pairs; rgbOut: 3 floats per listed pixel; vertexNormalsOut (optional): the normals the reference's
+//   TriangleMesh constructor generated (include/triangle.h:76-111), one per vertex of the input array.
+int ref_trace_diffuse(const float* verts, size_t nVerts, const int32_t* tris, size_t nTris, const float* spheres, size_t nSpheres,
+                      const float* albedo, const float* lightPos, const float* lightIntensity,
+                      const float* camPos, const float* camDir, float fov, int width, int height,
+                      const int32_t* pixels, size_t nPixels, int nthreads, float* rgbOut, float* vertexNormalsOut)
+{
+    std::vector<TriangleMesh> meshes;
+    const Spectrum alb(albedo[0], albedo[1], albedo[2]);
+    std::vector<int32_t> vertexBase;
+    size_t i = 0;
+    while (i < nTris) {                                       // as buildScene: one mesh per run of equal mesh ids
+        const int32_t mid = tris[i * 5 + 3];
+        size_t j = i;
+        int32_t vmin = std::numeric_limits<int32_t>::max(), vmax = -1;
+        while (j < nTris && tris[j * 5 + 3] == mid) {
+            for (int c = 0; c < 3; ++c) { vmin = std::min(vmin, tris[j * 5 + c]); vmax = std::max(vmax, tris[j * 5 + c]); }
+            ++j;
+        }
+        if (mid != (int32_t)meshes.size() || vmin < 0 || vmax >= (int64_t)nVerts) return -1;
+        std::vector<Vector3f> v;
+        for (int32_t k = vmin; k <= vmax; ++k) v.emplace_back(verts[k * 3 + 0], verts[k * 3 + 1], verts[k * 3 + 2]);
+        std::vector<Triangle> t;
+        for (size_t k = i; k < j; ++k) t.emplace_back(tris[k * 5 + 0] - vmin, tris[k * 5 + 1] - vmin, tris[k * 5 + 2] - vmin);
+        meshes.emplace_back(v, t, std::make_shared<Lambertian>(alb));
+        vertexBase.push_back(vmin);
+        i = j;
+    }
+    std::vector<std::shared_ptr<Shape>> shapes;
+    for (size_t k = 0; k < nSpheres; ++k)
+        shapes.push_back(std::make_shared<Sphere>(spheres[k * 4 + 3], Vector3f(spheres[k * 4 + 0], spheres[k * 4 + 1], spheres[k * 4 + 2]), alb, Bxdf::Diff));
+    std::vector<std::shared_ptr<Light>> lights{ std::make_shared<PointLight>(
+        Vector3f(lightPos[0], lightPos[1], lightPos[2]), Spectrum(lightIntensity[0], lightIntensity[1], lightIntensity[2])) };
+    Scene scene(meshes, shapes, lights);
+    scene.accel_ = std::make_shared<BvhAccel>(scene);        // include/scene.h:73 without the TriAccel8 path
+    if (vertexNormalsOut) {
+        std::memset(vertexNormalsOut, 0, nVerts * 12);
+        for (size_t m = 0; m < scene.meshes_.size(); ++m) {
+            const auto& nrm = scene.meshes_[m].normals_;
+            for (size_t k = 0; k < nrm.size(); ++k) {
+                float* o = vertexNormalsOut + (size_t)(vertexBase[m] + (int32_t)k) * 3;
+                o[0] = nrm[k].x; o[1] = nrm[k].y; o[2] = nrm[k].z;
+            }
+        }
+    }
+    Camera camera(Vector3f(camPos[0], camPos[1], camPos[2]), normal(Vector3f(camDir[0], camDir[1], camDir[2])), width, height, fov);
+    parallelFor1(nPixels, nthreads, [&](size_t p) { trace(scene, camera, pixels[p * 2 + 0], pixels[p * 2 + 1]); });
+    for (size_t p = 0; p < nPixels; ++p) {
+        const RGBColor& c = camera.sensor_.buffer_[(size_t)pixels[p * 2 + 1] * width + pixels[p * 2 + 0]];
+        rgbOut[p * 3 + 0] = c.r; rgbOut[p * 3 + 1] = c.g; rgbOut[p * 3 + 2] = c.b;
+    }
+    return 0;
+}
+
 void* ref_scene_create(const float* verts, size_t nVerts, const int32_t* tris, size_t nTris,
                        const float* spheres, size_t nSpheres, int genNormals)
 {

@@ -190,7 +190,12 @@ __global__ void __launch_bounds__(256) wfShade(WfBuffers B, DiffuseParams J, uin
             const float t = s0.w;
             const float Px = o.x + d.x * t, Py = o.y + d.y * t, Pz = o.z + d.z * t;            // :72
             const bool front = s0.x * d.x + s0.y * d.y + s0.z * d.z < 0.0f;                      // :74
-            const float nlx = front ? s0.x : -s0.x, nly = front ? s0.y : -s0.y, nlz = front ? s0.z : -s0.z;
+            // :73-74: nl is the SHADING normal (not normalised, include/triangle.h:166-171), turned by the sign of the
+            // geometric one.  A scene given without vertex normals (all zero) is flat shaded: the geometric normal.
+            const float4 s1 = B.surf[(size_t)i * 3 + 1];          // shading normal, u
+            const bool flat = s1.x == 0.0f && s1.y == 0.0f && s1.z == 0.0f;
+            const float snx = flat ? s0.x : s1.x, sny = flat ? s0.y : s1.y, snz = flat ? s0.z : s1.z;
+            const float nlx = front ? snx : -snx, nly = front ? sny : -sny, nlz = front ? snz : -snz;
             // light sample (include/light.h:41-52), shadow ray (:101-102; the point light's eps is 0)
             const float tx = J.light[0] - Px, ty = J.light[1] - Py, tz = J.light[2] - Pz;
             const float dist2 = tx * tx + ty * ty + tz * tz;
@@ -217,7 +222,7 @@ __global__ void __launch_bounds__(256) wfShade(WfBuffers B, DiffuseParams J, uin
                     const float ay = 2.0f * rnd(key, dim + 5u + 2u * k) - 1.0f;
                     if (ax * ax + ay * ay <= 1.0f) { lx = ax; ly = ay; break; }
                 }
-                const float lz = sqrtf(fmaxf(0.0f, 1.0f - lx * lx - ly * ly));
+                float lz = sqrtf(fmaxf(0.0f, 1.0f - lx * lx - ly * ly));
                 // include/frame.h:18-32
                 const float invN = 1.0f / sqrtf(nlx * nlx + nly * nly + nlz * nlz);
                 const float nx = nlx * invN, ny = nly * invN, nz = nlz * invN;
@@ -230,12 +235,21 @@ __global__ void __launch_bounds__(256) wfShade(WfBuffers B, DiffuseParams J, uin
                     fx = 0.0f; fy = nz * il; fz = -ny * il;
                 }
                 const float sx = ny * fz - nz * fy, sy = nz * fx - nx * fz, sz = nx * fy - ny * fx;   // s = cross(n, t)
+                // Lambertian::sample (src/bsdf.cpp:86-95): the sampled direction lies on wo's side of the frame (wo.z =
+                // dot(-dir, n) is negative only where the shading normal disagrees with the geometric one); a direction
+                // within EPS of the horizon ends the path (:92-93 -> src/renderer.cpp:121-122)
+                const float pdfL = lz * kInvPi;
+                if (-(d.x * nx + d.y * ny + d.z * nz) < 0.0f) lz = -lz;
                 const float ddx = lx * sx + ly * fx + lz * nx;                                         // toWorld
                 const float ddy = lx * sy + ly * fy + lz * ny;
                 const float ddz = lx * sz + ly * fz + lz * nz;
-                if (lz == 0.0f) goesOn = false;                                                        // :121-122 (refl.y() == 0)
+                if (fabsf(lz) < kEps) goesOn = false;
                 else {
-                    w.x = w.x * J.albedo[0]; w.y = w.y * J.albedo[1]; w.z = w.z * J.albedo[2];       // refl |cos| / pdf = albedo
+                    // src/renderer.cpp:128: pathWeight * refl * |dot(dir, nl)| / pdf, nl as it is (not normalised)
+                    const float cosW = fabsf(ddx * nlx + ddy * nly + ddz * nlz);
+                    w.x = w.x * (J.albedo[0] * kInvPi) * cosW / pdfL;
+                    w.y = w.y * (J.albedo[1] * kInvPi) * cosW / pdfL;
+                    w.z = w.z * (J.albedo[2] * kInvPi) * cosW / pdfL;
                     B.rays[(size_t)i * 2 + 0] = make_float4(Px + ddx * kEps, Py + ddy * kEps, Pz + ddz * kEps, 0.0f);
                     B.rays[(size_t)i * 2 + 1] = make_float4(ddx, ddy, ddz, __builtin_inff());
                 }
