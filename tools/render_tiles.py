@@ -39,7 +39,8 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--spp", type=int, default=2)
     ap.add_argument("--depth", type=int, default=8)
-    ap.add_argument("--slots", type=int, default=1 << 22)
+    ap.add_argument("--slots", type=int, default=1 << 23,
+                    help="path slots = rays per batch and rank; 2^23 keeps every rank of an 8-way split in the throughput regime (DESIGN.md 5)")
     ap.add_argument("--verify", action="store_true")
     ap.add_argument("--oracle-pixels", type=int, default=512, help="pixels per rank re-rendered on the CPU with --verify")
     ap.add_argument("--out", default="")
