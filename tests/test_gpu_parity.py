@@ -296,6 +296,29 @@ def test_concurrent_submissions_on_distinct_streams():
     assert not errors, errors
 
 
+@pytest.mark.parametrize("pool", ["11,10,512", "5,6,256"])
+def test_phase_pool_kernel_returns_the_default_kernels_hits(golden, monkeypatch, pool):
+    """The experiment kernel behind YART_WIDE_POOL (rays move between the waves of a workgroup so that a wave step holds
+    rays of one phase) is another schedule of the same tests: its hits are the default kernel's bit for
+    bit -- on the golden sets of the real reference (ties, edge cases, irregular rays that go to the fix-up launches) and
+    on a soup with spheres whose deeper stacks leave the LDS window."""
+    g = golden
+    v, t, s = scenes.random_soup(150000, 20000, s=0.02, seed=31)
+    cases = [(api.Accel(g["verts"], g["tris"], g["spheres"]), dev(g["rays"])),
+             (api.Accel(v, t, s), dev(scenes.random_rays(1 << 18, seed=32)))]
+    for acc, rays in cases:
+        want = acc.intersect_closest(rays, api.YART_SORT_RAYS).clone()
+        slots, window, block = pool.split(",")
+        monkeypatch.setenv("YART_WIDE_POOL", slots)
+        monkeypatch.setenv("YART_WIDE_POOL_WINDOW", window)
+        monkeypatch.setenv("YART_WIDE_POOL_BLOCK", block)
+        for flags in (api.YART_SORT_RAYS, 0):
+            got = acc.intersect_closest(rays, flags)
+            assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+        monkeypatch.delenv("YART_WIDE_POOL")
+        acc.close()
+
+
 def test_sort_threshold_is_a_pure_performance_policy(monkeypatch):
     """With the default YART_SORT_MIN_RAYS a small batch is not sorted, a large one is; results are the
     same as with the threshold lifted (sorting never changes an answer)."""

@@ -224,6 +224,23 @@ int runIntersect(YartAccel* a, const Launch& L, const CallScratch* given)
         W.cullReach = a->cullReach;
         W.cullMargin = 0x1p-21f * a->cullReach;
         W.refillMin = a->wideRefillMin; W.nodeMin = a->wideNodeMin; W.sphereMin = a->wideSphereMin; W.chunk = a->wideChunk; W.maxBlocksPerCU = a->wideBlocksPerCU; W.laneCap = a->wideLaneCap; W.hasSpheres = a->numSpheres > 0 ? 1u : 0u;
+        if (!given) {
+            // experiment flags, read per call
+            static const auto envU = [](const char* name, uint32_t dflt) { const char* v = std::getenv(name); return v ? static_cast<uint32_t>(std::atoi(v)) : dflt; };
+            W.poolSlots = envU("YART_WIDE_POOL", 0);
+            if (W.poolSlots) {
+                W.poolWindow = envU("YART_WIDE_POOL_WINDOW", 10);
+                W.poolBlock = envU("YART_WIDE_POOL_BLOCK", 512);
+                W.poolKeep = envU("YART_WIDE_POOL_KEEP", 48);
+                W.poolTriMin = envU("YART_WIDE_POOL_TRI", 32);
+                W.poolSphMin = envU("YART_WIDE_POOL_SPH", 24);
+                if (W.poolBlock != 256 && W.poolBlock != 512) W.poolBlock = 512;
+                if (W.poolSlots > 32) W.poolSlots = 32;
+                if (W.poolSlots <= W.poolBlock / 64) W.poolSlots = W.poolBlock / 64 + 1;      // a wave must always find a slot
+                if (W.poolWindow < 2) W.poolWindow = 2;
+                if (W.poolWindow > 32) W.poolWindow = 32;
+            }
+        }
         {
             ScopedSpan span(a, 2, L.stream, !given);
             e = yart::launchTraceWide(W, L.any, L.count, persistent, a->numCUs, L.stream);

@@ -83,6 +83,9 @@ struct WideParams {
     float cullReach;            // max over the axes of (longest way from a covered origin to the far side of the tree's bounds
                                 // + 1.25 x their extent): |A| + 255 |B| of slab4 <= cullReach x the largest |1 / d|
     float cullMargin;           // 2^-21 cullReach
+    // experiment (YART_WIDE_POOL, traverse_wide.hip: tracePool): slots per lane class (0: off), stack entries per slot in
+    // LDS, threads per block, lanes at interior nodes below which a wave goes back to the masks, leaf-step thresholds
+    uint32_t poolSlots, poolWindow, poolBlock, poolKeep, poolTriMin, poolSphMin;
 };
 
 hipError_t launchTraceWide(const WideParams& P, bool any, bool count, bool persistent, int numCUs,

@@ -587,6 +587,390 @@ hipError_t launchW(const WideParams& P, bool persistent, int numCUs, hipStream_t
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// tracePool -- EXPERIMENT (YART_WIDE_POOL=S, closest hit only): phase-homogeneous wave steps.  The rays of a workgroup
+// live in a pool of S slots per lane CLASS (slot index = s * 64 + lane: every LDS array is indexed so that lane L only
+// ever touches bank L -- conflict-free -- and a ray never changes its lane, only the wave that works on it).  Per class
+// four bit masks say which slots wait for a node step, a triangle test, a sphere test, or are free.  A wave looks at the
+// masks, picks the phase most of its lanes can take part in, parks the rays it holds in another phase (two LDS writes and
+// an atomic or) and claims waiting ones of the chosen phase (atomic and), so a node step runs with rays at interior
+// nodes in (nearly) all 64 lanes and a leaf step with leaves in most.  No speculative descent: a ray is in one phase.
+// What it costs: the state of a claimed ray comes out of LDS (11 reads + three reciprocals), LDS holds the whole ray
+// state (27 dwords per slot with a 10-entry stack window, deeper entries in a global overflow area), so fewer rays are
+// in flight per CU, and the claim / park code is issued nearly every time the wave comes back to the top.
+// Results are the default kernel's bit for bit (order independence).  Numbers: DESIGN.md 3.9.
+enum { PF_OX, PF_OY, PF_OZ, PF_DX, PF_DY, PF_DZ, PF_TMAX, PF_TTRI, PF_HU, PF_HV, PF_PRIM, PF_CUR, PF_SP, PF_RAY, PF_F, PF_MINS, PF_MAXL, PF_COUNT };
+constexpr int kPoolBlockMax = 512;
+enum { PH_NONE = 0, PH_NODE = 1, PH_TRI = 2, PH_SPH = 3 };
+
+template <bool SPH>
+__global__ void __launch_bounds__(kPoolBlockMax) tracePool(WideParams P, uint32_t* __restrict__ ovfAll)
+{
+    extern __shared__ uint32_t pl[];
+    const uint32_t S = P.poolSlots, W = P.poolWindow, NS = S * 64u;
+    uint32_t* const masks = pl + PF_COUNT * NS;          // [node, tri, sph, free][64]
+    uint32_t* const stack = masks + 256;                 // [W][NS]
+    uint32_t* const ovf = ovfAll + (size_t)blockIdx.x * NS * kWideStack;
+    float* const pf = reinterpret_cast<float*>(pl);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint64_t laneBit = 1ull << lane;
+    if (tid < 64) { masks[tid] = 0; masks[64 + tid] = 0; masks[128 + tid] = 0; masks[192 + tid] = (S >= 32 ? 0xFFFFFFFFu : ((1u << S) - 1u)); }
+    __syncthreads();
+
+    WRay r;
+    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = r.tmax = 0.0f;
+    bool have = false;
+    uint32_t si = (uint32_t)lane;          // slot index of the ray held
+    uint32_t cur = kIdle;
+    int sp = 0;
+    float bnd = 0.0f;                      // min(best triangle t, best sphere float t) of the ray held
+
+    uint32_t chunkNext = 0, chunkEnd = 0;
+    bool exhausted = false;
+    const uint32_t homeXcd = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;
+    uint32_t rangesDone = 0;
+    const uint32_t kChunk = P.chunk;
+    const int refillMin = (int)P.refillMin, nodeMin = (int)P.nodeMin, nodeKeep = (int)P.poolKeep;
+    const int triMin = (int)P.poolTriMin, sphMin = (int)P.poolSphMin;
+#ifdef YART_STEP_STATS
+    uint32_t stNodeSteps = 0, stNodeLanes = 0, stLeafSteps = 0, stLeafLanes = 0, stIters = 0, stSphSteps = 0, stSphLanes = 0, stStart = 0;
+#endif
+
+    auto push = [&](uint32_t v) {
+        if ((uint32_t)sp < W) stack[(uint32_t)sp * NS + si] = v;
+        else __hip_atomic_store(ovf + (size_t)si * kWideStack + (sp - (int)W), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ++sp;
+    };
+    auto pop = [&]() -> uint32_t {
+        if (sp == 0) return kIdle;
+        --sp;
+        if (__builtin_expect((uint32_t)sp < W, 1)) return stack[(uint32_t)sp * NS + si];
+        // written by whichever wave held the ray then: read past this CU's L1
+        return __hip_atomic_load(ovf + (size_t)si * kWideStack + (sp - (int)W), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto phaseOf = [&](uint32_t c) -> int {
+        if (c == kIdle) return PH_NONE;
+        if ((c & kPackLeaf) == 0) return PH_NODE;
+        return (SPH && (c & kPackSphere)) ? PH_SPH : PH_TRI;
+    };
+    auto park = [&](int ph) {
+        pl[PF_CUR * NS + si] = cur;
+        pl[PF_SP * NS + si] = (uint32_t)sp;
+        __hip_atomic_fetch_or(masks + (ph - 1) * 64 + lane, 1u << (si >> 6), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        have = false;
+    };
+    auto claim = [&](int ph, uint32_t m) {
+        const uint32_t b = (uint32_t)__builtin_ctz(m);
+        const uint32_t old = __hip_atomic_fetch_and(masks + (ph - 1) * 64 + lane, ~(1u << b), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!(old & (1u << b))) return;                  // another wave was faster
+        si = b * 64u + (uint32_t)lane;
+        have = true;
+        r.ox = pf[PF_OX * NS + si]; r.oy = pf[PF_OY * NS + si]; r.oz = pf[PF_OZ * NS + si];
+        r.dx = pf[PF_DX * NS + si]; r.dy = pf[PF_DY * NS + si]; r.dz = pf[PF_DZ * NS + si];
+        r.tmax = pf[PF_TMAX * NS + si];
+        r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
+        cur = pl[PF_CUR * NS + si];
+        sp = (int)pl[PF_SP * NS + si];
+        const float tt = pf[PF_TTRI * NS + si];
+        bnd = SPH ? fminf(tt, pf[PF_F * NS + si]) : tt;
+    };
+    auto deferRay = [&](uint32_t id) {
+        uint32_t c = __hip_atomic_load(P.deferFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c < P.deferCap) c = atomicAdd(P.deferFlag, 1u);
+        if (c < P.deferCap) P.deferList[c] = id;
+        else P.deferFlag[1] = 1u;
+        P.hits[id] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(kUnresolvedPrim));
+    };
+    // `si` names a free slot this lane has claimed; false: the ray is answered or deferred, the slot stays free
+    auto startRay = [&](uint32_t slot) -> bool {
+        const uint32_t rayId = P.perm ? P.perm[slot] : slot;
+        const float4 a = P.rays[(size_t)rayId * 2 + 0];
+        const float4 b = P.rays[(size_t)rayId * 2 + 1];
+        if (!(b.w > 0.0001f) && b.w == b.w) {
+            P.hits[rayId] = make_float4(b.w, 0.0f, 0.0f, __int_as_float(-1));
+            return false;
+        }
+        if (!regularRay(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w) || !coverHolds(P.cover, a.x, a.y, a.z)) { deferRay(rayId); return false; }
+        r.ox = a.x; r.oy = a.y; r.oz = a.z;
+        r.dx = b.x; r.dy = b.y; r.dz = b.z; r.tmax = b.w;
+        r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
+        if (!(fmaxf(fmaxf(fabsf(r.ix), fabsf(r.iy)), fabsf(r.iz)) * P.cullReach < __builtin_inff())) { deferRay(rayId); return false; }
+        pf[PF_OX * NS + si] = r.ox; pf[PF_OY * NS + si] = r.oy; pf[PF_OZ * NS + si] = r.oz;
+        pf[PF_DX * NS + si] = r.dx; pf[PF_DY * NS + si] = r.dy; pf[PF_DZ * NS + si] = r.dz;
+        pf[PF_TMAX * NS + si] = r.tmax; pf[PF_TTRI * NS + si] = r.tmax;
+        pf[PF_HU * NS + si] = 0.0f; pf[PF_HV * NS + si] = 0.0f;
+        pl[PF_PRIM * NS + si] = 0xFFFFFFFFu;
+        pl[PF_RAY * NS + si] = rayId;
+        if (SPH) { pf[PF_F * NS + si] = __builtin_inff(); pl[PF_MINS * NS + si] = 0xFFFFFFFFu; pl[PF_MAXL * NS + si] = 0xFFFFFFFFu; }
+        bnd = r.tmax;
+        sp = 0;
+        cur = 0u;
+        return true;
+    };
+    auto retire = [&]() {
+        const float tTri = pf[PF_TTRI * NS + si];
+        float hu = pf[PF_HU * NS + si], hv = pf[PF_HV * NS + si];
+        const int32_t primTri = (int32_t)pl[PF_PRIM * NS + si];
+        const uint32_t rayId = pl[PF_RAY * NS + si];
+        float F = __builtin_inff();
+        int32_t minS = -1, maxL = -1;
+        if (SPH) { F = pf[PF_F * NS + si]; minS = (int32_t)pl[PF_MINS * NS + si]; maxL = (int32_t)pl[PF_MAXL * NS + si]; }
+        const bool sphere = SPH && (minS >= 0) && !(tTri < F);
+        float t = sphere ? F : tTri;
+        int32_t prim = sphere ? -((minS > maxL ? minS : maxL) + 2) : primTri;
+        if (!(t < r.tmax)) prim = -1;
+        if (sphere || prim == -1) { hu = 0.0f; hv = 0.0f; }
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const f32x4 h4 = { t, hu, hv, __int_as_float(prim) };
+        __builtin_nontemporal_store(h4, reinterpret_cast<f32x4*>(P.hits + rayId));
+        __hip_atomic_fetch_or(masks + 192 + lane, 1u << (si >> 6), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        have = false;
+    };
+
+    for (;;) {
+        if (have && cur == kIdle) retire();
+        const uint32_t mN = masks[lane], mT = masks[64 + lane], mS = SPH ? masks[128 + lane] : 0u, mF = masks[192 + lane];
+        const int ph = have ? phaseOf(cur) : PH_NONE;
+        const int nN = __popcll(__ballot(ph == PH_NODE || mN != 0));
+        const int nT = __popcll(__ballot(ph == PH_TRI || mT != 0));
+        const int nS = SPH ? __popcll(__ballot(ph == PH_SPH || mS != 0)) : 0;
+        const int nF = exhausted ? 0 : __popcll(__ballot(mF != 0));
+        int phase;           // 0 = start rays
+        if (nF >= refillMin) phase = 0;
+        else if (nN >= nodeMin) phase = PH_NODE;
+        else if (SPH && nS >= sphMin) phase = PH_SPH;
+        else if (nT >= triMin) phase = PH_TRI;
+        else if (nN > 0 && nN >= nT && nN >= nS) phase = PH_NODE;
+        else if (nT > 0 && nT >= nS) phase = PH_TRI;
+        else if (nS > 0) phase = PH_SPH;
+        else if (nF > 0) phase = 0;
+        else if (__ballot(have) == 0 && exhausted) break;
+        else continue;       // every slot of every class is in another wave's hands for the moment
+#ifdef YART_STEP_STATS
+        ++stIters;
+#endif
+
+        if (phase == 0) {
+            // ---------------------------------------------------------------- start rays in free slots
+            bool mine = false;
+            if (mF != 0) {
+                if (have) park(ph);
+                const uint32_t b = (uint32_t)__builtin_ctz(mF);
+                const uint32_t old = __hip_atomic_fetch_and(masks + 192 + lane, ~(1u << b), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (old & (1u << b)) { mine = true; si = b * 64u + (uint32_t)lane; }
+            }
+            const uint64_t takers = __ballot(mine);
+            const int nTake = __popcll(takers);
+            while (chunkNext == chunkEnd && !exhausted) {
+                const uint32_t range = (homeXcd + rangesDone) & 7u;
+                const uint32_t rBegin = rangeBegin(P.n, range, kChunk), rEnd = rangeBegin(P.n, range + 1, kChunk);
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(P.workCounter + range * 8, kChunk);
+                base = __builtin_amdgcn_readfirstlane(base) + rBegin;
+                if (base >= rEnd) { if (++rangesDone == 8) exhausted = true; }
+                else { chunkNext = base; chunkEnd = (rEnd - base < kChunk) ? rEnd : base + kChunk; }
+            }
+            bool started = false;
+            if (!exhausted) {
+                const uint32_t avail = chunkEnd - chunkNext;
+                const uint32_t rank = __popcll(takers & (laneBit - 1));
+                if (mine && rank < avail) started = startRay(chunkNext + rank);
+                chunkNext += ((uint32_t)nTake < avail) ? (uint32_t)nTake : avail;
+            }
+            if (mine) {
+                if (started) have = true;
+                else __hip_atomic_fetch_or(masks + 192 + lane, 1u << (si >> 6), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+#ifdef YART_STEP_STATS
+            ++stStart;
+#endif
+            continue;
+        }
+
+        if (have && ph != phase) park(ph);
+        if (!have) {
+            const uint32_t m = phase == PH_NODE ? mN : (phase == PH_TRI ? mT : mS);
+            if (m != 0) claim(phase, m);
+        }
+
+        if (phase == PH_NODE) {
+            // ---------------------------------------------------------------- node steps
+            for (;;) {
+                const bool inner = have && (cur & kPackLeaf) == 0;       // kIdle has the leaf bit
+                const uint64_t im = __ballot(inner);
+                if (im == 0) break;
+#ifdef YART_STEP_STATS
+                ++stNodeSteps; stNodeLanes += __popcll(im);
+#endif
+                if (inner) {
+                    const float4* p = P.units + (cur >> 2);
+                    const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+                    __builtin_amdgcn_s_setprio(0);
+                    const float bound = bnd * kCullSlack;
+                    float tn[4];
+                    uint32_t rf[4];
+                    const uint32_t blk = __float_as_uint(q2.z), offs = __float_as_uint(q2.w);
+                    rf[0] = blk + (offs & 255u); rf[1] = blk + ((offs >> 8) & 255u);
+                    rf[2] = blk + ((offs >> 16) & 255u); rf[3] = blk + (offs >> 24);
+                    bool h[4];
+                    slab4(q0, q1, q2, r, bound, P.cullMargin, tn, h);
+                    const float inf = __builtin_inff();
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) tn[c] = h[c] ? tn[c] : inf;
+                    YART_CSWAP(0, 1) YART_CSWAP(2, 3) YART_CSWAP(0, 2) YART_CSWAP(1, 3) YART_CSWAP(1, 2)
+                    __builtin_amdgcn_s_setprio(2);
+                    if (tn[3] < inf) push(rf[3]);
+                    if (tn[2] < inf) push(rf[2]);
+                    if (tn[1] < inf) push(rf[1]);
+                    cur = (tn[0] < inf) ? rf[0] : pop();
+                }
+                if (__popcll(__ballot(have && (cur & kPackLeaf) == 0)) < nodeKeep) break;
+            }
+            continue;
+        }
+
+        if (phase == PH_TRI) {
+            // ---------------------------------------------------------------- one triangle leaf per lane
+            const bool act = have && cur != kIdle && (cur & kPackLeaf) && !(SPH && (cur & kPackSphere));
+#ifdef YART_STEP_STATS
+            { const uint64_t pm = __ballot(act); if (pm) { ++stLeafSteps; stLeafLanes += __popcll(pm); } }
+#endif
+            uint32_t tieRow = kIdle;
+            float tTri = 0.0f, hu = 0.0f, hv = 0.0f;
+            int32_t primTri = -1;
+            if (act) {
+                const uint32_t leaf = cur;
+                tTri = pf[PF_TTRI * NS + si];
+                primTri = (int32_t)pl[PF_PRIM * NS + si];
+                const float4* row = P.units + (leaf >> 2);
+                do {
+                    const float4 A = row[0];
+                    const uint32_t kw = __float_as_uint(A.w);
+                    const int k = (int)(kw & 3u);
+                    const float dk = sel3(k, r.dx, r.dy, r.dz), du = sel3(k, r.dy, r.dz, r.dx), dv = sel3(k, r.dz, r.dx, r.dy);
+                    const float ok = sel3(k, r.ox, r.oy, r.oz), ou = sel3(k, r.oy, r.oz, r.ox), ov = sel3(k, r.oz, r.ox, r.oy);
+                    const float nd = 1.0f / (dk + A.x * du + A.y * dv);
+                    const float t = (A.z - ok - A.x * ou - A.y * ov) * nd;
+                    const uint32_t slot = (kw & kPackSlotMask) >> 2;
+                    if (!(bnd > t && t > 0.0001f)) {
+                        if (t == tTri && primTri >= 0 && (int32_t)slot != primTri) tieRow = leaf;
+                        break;
+                    }
+                    const float4* ta = P.triaccel + (size_t)slot * 3;
+                    const float4 B = ta[1], C = ta[2];
+                    const float phu = ou + t * du;
+                    const float phv = ov + t * dv;
+                    const float lambda = phu * B.x + phv * B.y + B.z;
+                    if (lambda < 0.0f) break;
+                    const float mue = phu * C.x + phv * C.y + C.z;
+                    if (mue < 0.0f) break;
+                    if (lambda + mue > 1.0f) break;
+                    if (kw >> kPackBandShift) {
+                        if (fminf(fminf(lambda, mue), 1.0f - (lambda + mue)) < bandOfClass(kw >> kPackBandShift)) {
+                            const float4* lb = P.refNodes + 2 * (size_t)P.leafOfSlot[slot];
+                            const float4 b0 = lb[0], b1 = lb[1];
+                            if (!slabRef(b0, b1, r)) break;
+                        }
+                    }
+                    tTri = t; bnd = t;
+                    pf[PF_TTRI * NS + si] = t; pf[PF_HV * NS + si] = lambda; pf[PF_HU * NS + si] = mue;
+                    pl[PF_PRIM * NS + si] = slot;
+                } while (false);
+            }
+            if (__ballot(tieRow != kIdle) != 0) {
+                if (tieRow != kIdle) {
+                    hu = pf[PF_HU * NS + si]; hv = pf[PF_HV * NS + si];
+                    const int32_t before = primTri;
+                    tieBreak(P, r, tieRow, tTri, hu, hv, primTri);
+                    if (primTri != before) { pf[PF_HU * NS + si] = hu; pf[PF_HV * NS + si] = hv; pl[PF_PRIM * NS + si] = (uint32_t)primTri; }
+                }
+            }
+            if (act) cur = pop();
+            continue;
+        }
+
+        // -------------------------------------------------------------------- one sphere leaf per lane
+        if (SPH) {
+            const bool act = have && cur != kIdle && (cur & kPackLeaf) && (cur & kPackSphere);
+#ifdef YART_STEP_STATS
+            { const uint64_t sm = __ballot(act); if (sm) { ++stSphSteps; stSphLanes += __popcll(sm); } }
+#endif
+            if (act) {
+                const float4* row = P.units + (cur >> 2);
+                do {
+                    const float4 Sr = row[0];
+                    const float opx = Sr.x - r.ox, opy = Sr.y - r.oy, opz = Sr.z - r.oz;
+                    const double b = (double)(opx * r.dx + opy * r.dy + opz * r.dz);
+                    double det = b * b - (double)(opx * opx + opy * opy + opz * opz) + (double)(Sr.w * Sr.w);
+                    if (det < 0) break;
+                    det = sqrt(det);
+                    const double eps = (double)1e-4f;
+                    double t = b - det;
+                    if (!(t > eps)) t = b + det;
+                    if (!(t > eps && t < (double)r.tmax)) break;
+                    const float f = (float)t;
+                    if (f > bnd) break;
+                    const int32_t idx = (int32_t)__float_as_uint(row[1].x);
+                    const bool below = t < (double)f;
+                    const float F = pf[PF_F * NS + si];
+                    int32_t minS = (int32_t)pl[PF_MINS * NS + si], maxL = (int32_t)pl[PF_MAXL * NS + si];
+                    if (minS < 0 || f < F) { pf[PF_F * NS + si] = f; minS = idx; maxL = below ? idx : -1; bnd = f; }
+                    else {
+                        minS = (idx < minS) ? idx : minS;
+                        if (below && idx > maxL) maxL = idx;
+                    }
+                    pl[PF_MINS * NS + si] = (uint32_t)minS; pl[PF_MAXL * NS + si] = (uint32_t)maxL;
+                } while (false);
+                cur = pop();
+            }
+        }
+    }
+#ifdef YART_STEP_STATS
+    if (lane == 0) {
+        atomicAdd(P.workCounter + 9, stNodeSteps); atomicAdd(P.workCounter + 10, stNodeLanes >> 6);
+        atomicAdd(P.workCounter + 11, stLeafSteps); atomicAdd(P.workCounter + 12, stLeafLanes >> 6);
+        atomicAdd(P.workCounter + 13, stIters); atomicAdd(P.workCounter + 14, stStart);
+        atomicAdd(P.workCounter + 17, stSphSteps); atomicAdd(P.workCounter + 18, stSphLanes);
+    }
+#endif
+}
+
+template <bool SPH>
+hipError_t launchPool(const WideParams& P, int numCUs, hipStream_t stream)
+{
+    if (P.n == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(P.workCounter, 0, 256, stream);
+    if (e != hipSuccess) return e;
+    const uint32_t NS = P.poolSlots * 64u;
+    const size_t lds = ((size_t)PF_COUNT * NS + 256 + (size_t)P.poolWindow * NS) * 4;
+    const int perCU = (int)(163840 / lds) < 1 ? 1 : (int)(163840 / lds);
+    const uint32_t grid = (uint32_t)numCUs * (uint32_t)perCU;
+    // experiment: one overflow area per device, sized for the largest launch so far; launches of this kernel must not overlap
+    static uint32_t* ovf[16] = {};
+    static size_t ovfBytes[16] = {};
+    int dev = 0;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+    const size_t need = (size_t)grid * NS * kWideStack * 4;
+    if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+    if (need > ovfBytes[dev]) {
+        if (ovf[dev]) (void)hipFree(ovf[dev]);
+        ovf[dev] = nullptr; ovfBytes[dev] = 0;
+        if ((e = hipMalloc(reinterpret_cast<void**>(&ovf[dev]), need)) != hipSuccess) return e;
+        ovfBytes[dev] = need;
+    }
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(tracePool<SPH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL((tracePool<SPH>), dim3(grid), dim3(P.poolBlock), lds, stream, P, ovf[dev]);
+#ifdef YART_STEP_STATS
+    uint32_t st[12];
+    if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(st + 2, P.workCounter + 9, 10 * 4, hipMemcpyDeviceToHost) == hipSuccess && P.n > 1000000)
+        fprintf(stderr, "pool step stats (%u rays, S=%u W=%u block=%u x%d per CU, lds %zu): node steps %u, mean lanes %.1f; triangle leaf steps %u, mean lanes %.1f; sphere leaf steps %u, mean lanes %.1f; top-of-loop passes %u, start steps %u\n",
+                P.n, P.poolSlots, P.poolWindow, P.poolBlock, perCU, lds, st[2], 64.0 * st[3] / (st[2] ? st[2] : 1), st[4], 64.0 * st[5] / (st[4] ? st[4] : 1), st[10], (double)st[11] / (st[10] ? st[10] : 1), st[6], st[7]);
+#endif
+    return hipGetLastError();
+}
+
 // The leaf of every triangle slot in the reference's flattened node array (the near-edge check and the tie rule above).
 __global__ void __launch_bounds__(256) leafOfSlotKernel(const uint4* __restrict__ nodes, uint32_t numNodes, uint32_t* __restrict__ leafOfSlot)
 {
@@ -611,6 +995,8 @@ hipError_t launchLeafOfSlot(const void* nodes, size_t numNodes, uint32_t* leafOf
 hipError_t launchTraceWide(const WideParams& P, bool any, bool count, bool persistent, int numCUs,
                            hipStream_t stream)
 {
+    if (P.poolSlots && !any && !count && persistent)
+        return P.hasSpheres ? launchPool<true>(P, numCUs, stream) : launchPool<false>(P, numCUs, stream);
     if (P.hasSpheres) {
         if (any) return count ? launchW<true, true, true>(P, persistent, numCUs, stream) : launchW<true, false, true>(P, persistent, numCUs, stream);
         return count ? launchW<false, true, true>(P, persistent, numCUs, stream) : launchW<false, false, true>(P, persistent, numCUs, stream);
