@@ -105,20 +105,11 @@ def main():
         # SURVEY 8e throughput mode: the batch every rank holds is ordered ONCE by the coherence key (Morton cell of the
         # origin on a 128^3 grid over the scene + direction octant, as sort.hip) and cut into contiguous slices, so a rank's
         # rays stay in one region of the scene; outside the timed region (the caller's batch arrives ordered).
-        d_all = torch.from_numpy(rays).cuda()
-        lo = torch.from_numpy(verts.min(0)).cuda()
-        hi = torch.from_numpy(verts.max(0)).cuda()
-        q = ((d_all[:, 0:3] - lo) / (hi - lo) * 128.0).clamp_(0, 127).to(torch.int64)
-        key = torch.zeros(args.rays, dtype=torch.int64, device="cuda")
-        for bit in range(7):
-            for ax in range(3):
-                key |= ((q[:, ax] >> bit) & 1) << (3 * bit + ax + 3)
-        key |= (d_all[:, 4] < 0).to(torch.int64) | ((d_all[:, 5] < 0).to(torch.int64) << 1) | ((d_all[:, 6] < 0).to(torch.int64) << 2)
-        order = torch.argsort(key, stable=True)
         from yart_amd import shard
-        begin, end = shard.ray_slice(args.rays, rank, world)
-        rays = d_all[order[begin:end]].cpu().numpy()
-        del d_all, q, key, order
+        d_all = torch.from_numpy(rays).cuda()
+        order, _ = shard.strong_slice(d_all, verts.min(0), verts.max(0), rank, world)
+        rays = d_all[order].cpu().numpy()
+        del d_all, order
         torch.cuda.empty_cache()
         args.rays = len(rays)
     if rank == 0:

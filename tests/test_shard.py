@@ -83,3 +83,43 @@ def test_gloo_world2_gather_equals_single_rank(tmp_path, w, h):
     pix = shard.tile_pixels(tiles, shard.tiles_of_rank(len(tiles), 0, 1), w)
     one = shard.gather_framebuffer(torch.from_numpy(_pixel_value(pix)), w, h, 0, 1).numpy()
     assert np.array_equal(one.view(np.uint32), want.view(np.uint32))
+
+
+def _strong_worker(rank, world, port, n, out_path):
+    import torch.distributed as dist
+    from yart_amd import scenes
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rays = torch.from_numpy(scenes.random_rays(n, seed=5))          # the ONE batch, the same on every rank
+    ids, keys = shard.strong_slice(rays, [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], rank, world)
+    assert bool((keys[1:] >= keys[:-1]).all())                      # a slice of the ordered batch is ordered
+    sums = torch.tensor([ids.numel(), int(ids.sum()), int((ids * ids % 1000003).sum()), rank + 1], dtype=torch.int64)
+    shard.allreduce_u64(sums)
+    edges = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(edges, torch.stack([keys.min(), keys.max()]))
+    if rank == 0:
+        np.save(out_path, np.concatenate([sums.numpy(), torch.stack(edges).numpy().ravel()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_strong_scaling_slices_and_counter_reduction(tmp_path):
+    """bench.py --scaling strong on two ranks, rehearsed on CPU: every ray of the one batch belongs to exactly one rank
+    (count, sum and a checksum of the ray numbers reduced over the ranks, the job of yart_comm_allreduce_u64 on GPUs),
+    and the slices are contiguous pieces of the coherence order (rank 0's keys end where rank 1's begin)."""
+    import torch.multiprocessing as mp
+    n, world = 100003, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "strong.npy")
+    mp.spawn(_strong_worker, args=(world, port, n, out), nprocs=world, join=True)
+    got = np.load(out)
+    ids = np.arange(n, dtype=np.int64)
+    assert got[:4].tolist() == [n, int(ids.sum()), int((ids * ids % 1000003).sum()), 3]
+    assert got[4 + 1] <= got[4 + 2]                                 # max key of rank 0 <= min key of rank 1
+    # world == 1: the whole batch, no process group
+    rays = torch.from_numpy(__import__("yart_amd.scenes", fromlist=["x"]).random_rays(1000, seed=1))
+    one, keys = shard.strong_slice(rays, [0.0] * 3, [1.0] * 3, 0, 1)
+    assert sorted(one.tolist()) == list(range(1000)) and shard.allreduce_u64(torch.tensor([7])).tolist() == [7]

@@ -71,6 +71,41 @@ def ray_slice(n, rank, world):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+def coherence_key(rays, lo, hi, grid_bits=7):
+    """The library's sort key (sort.hip: Morton cell of the origin on a 2^grid_bits grid over [lo, hi], direction octant
+    in the low three bits) as torch ops on whatever device `rays` [n, 8] lives on.  Strong scaling orders ONE
+    batch by it once and cuts contiguous slices, `ray_slice`, one per rank: a slice of an ordered batch is ordered."""
+    import torch
+    lo = torch.as_tensor(lo, dtype=torch.float32, device=rays.device)
+    hi = torch.as_tensor(hi, dtype=torch.float32, device=rays.device)
+    cells = float(1 << grid_bits)
+    q = ((rays[:, 0:3] - lo) / (hi - lo) * cells).clamp_(0, cells - 1).to(torch.int64)
+    key = torch.zeros(rays.shape[0], dtype=torch.int64, device=rays.device)
+    for bit in range(grid_bits):
+        for ax in range(3):
+            key |= ((q[:, ax] >> bit) & 1) << (3 * bit + ax + 3)
+    key |= (rays[:, 4] < 0).to(torch.int64) | ((rays[:, 5] < 0).to(torch.int64) << 1) | ((rays[:, 6] < 0).to(torch.int64) << 2)
+    return key
+
+
+def strong_slice(rays, lo, hi, rank, world):
+    """This rank's rays of a batch every rank holds: -> (ray numbers of the slice in coherence order, keys of the slice)."""
+    import torch
+    key = coherence_key(rays, lo, hi)
+    order = torch.argsort(key, stable=True)
+    begin, end = ray_slice(rays.shape[0], rank, world)
+    return order[begin:end], key[order[begin:end]]
+
+
+def allreduce_u64(values, group=None):
+    """Counters / checksums summed over the ranks, in place (int64 tensor): what `yart_comm_allreduce_u64` does over RCCL,
+    through torch.distributed for ranks that share a GPU or run on CPU (gloo).  world == 1 needs no process group."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(values, op=dist.ReduceOp.SUM, group=group)
+    return values
+
+
 def gather_framebuffer(local_rgb, width, height, rank, world, tile=TILE, group=None):
     """local_rgb: float32 tensor [nLocalPixels, 3] in `tile_pixels(tiles, tiles_of_rank(..))` order
     (CPU tensor with gloo, GPU tensor with nccl/RCCL).  Returns the full [height, width, 3] frame
