@@ -336,6 +336,165 @@ __global__ void __launch_bounds__(64) treeletSah(const uint32_t* __restrict__ ro
     }
 }
 
+// The same splits by ONE WAVE per subtree (round 3; the one-thread form above took 60 ms of C4's build and stays for
+// treelets above kWaveTreelet).  The subtree's boxes sit in LDS; per range the wave reduces the bounds of the centres,
+// bins all three axes in one pass with LDS integer min / max on order-preserving keys (a box union does not depend on
+// the order of its operands, so the bins are the one-thread form's), evaluates the 45 candidate planes one per lane
+// with the one-thread form's expressions and takes the cheapest, ties to the earlier (axis, plane) like its loop, and
+// partitions stably by ballot ranks.  Same subtrees as sets of primitives; the order of the primitives inside a part
+// (and so the node numbers) is this kernel's own -- deterministic, and nothing downstream depends on it.
+constexpr int kWaveTreelet = 256;
+
+__device__ inline uint32_t orderedKey(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ inline float fromOrderedKey(uint32_t k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+__device__ inline float waveMinF(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
+__device__ inline float waveMaxF(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
+
+__global__ void __launch_bounds__(64) treeletSahWave(const uint32_t* __restrict__ roots, const uint32_t* __restrict__ nRoots,
+                                                     const uint32_t* __restrict__ rangeLo, const uint32_t* __restrict__ rangeHi, uint32_t nLeaves,
+                                                     uint32_t* __restrict__ sortedIds, const float4* __restrict__ primLo, const float4* __restrict__ primHi,
+                                                     uint32_t* __restrict__ left, uint32_t* __restrict__ right, uint32_t* __restrict__ parent)
+{
+    constexpr int T = kWaveTreelet, kBins = 16;
+    __shared__ float bl[3][T], bh[3][T];
+    __shared__ uint32_t ids[T], idx[T], tmp[T];
+    __shared__ uint32_t binLo[3][kBins][3], binHi[3][kBins][3], binCnt[3][kBins];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t total = *nRoots;
+    for (uint32_t t = blockIdx.x; t < total; t += gridDim.x) {
+        const uint32_t rootNode = roots[t];
+        const uint32_t f = rangeLo[rootNode], l = rangeHi[rootNode];
+        const uint32_t size = l - f + 1u;               // 3 .. T
+        __syncthreads();                                // one wave: orders this subtree's LDS writes after the last one's reads
+        for (uint32_t i = lane; i < size; i += 64u) {
+            const uint32_t id = sortedIds[f + i];
+            const float4 pl = primLo[id], ph = primHi[id];
+            bl[0][i] = pl.x; bl[1][i] = pl.y; bl[2][i] = pl.z;
+            bh[0][i] = ph.x; bh[1][i] = ph.y; bh[2][i] = ph.z;
+            ids[i] = id;
+            idx[i] = i;
+        }
+        __syncthreads();
+        uint32_t nextId = f + 1u;
+        struct Todo { uint32_t node, b, e; };
+        Todo stack[10];
+        int sp = 0;
+        Todo cur{ rootNode, 0u, size };
+        for (;;) {
+            const uint32_t count = cur.e - cur.b;       // >= 2
+            uint32_t mid = cur.b + count / 2u;
+            if (count > 2u) {
+                float cLo[3] = { __builtin_inff(), __builtin_inff(), __builtin_inff() }, cHi[3] = { -__builtin_inff(), -__builtin_inff(), -__builtin_inff() };
+                for (uint32_t i = cur.b + lane; i < cur.e; i += 64u) {
+                    const uint32_t j = idx[i];
+                    for (int a = 0; a < 3; ++a) { const float c = 0.5f * bl[a][j] + 0.5f * bh[a][j]; cLo[a] = fminf(cLo[a], c); cHi[a] = fmaxf(cHi[a], c); }
+                }
+                float scale[3];
+                bool use[3];
+                for (int a = 0; a < 3; ++a) {
+                    cLo[a] = waveMinF(cLo[a]); cHi[a] = waveMaxF(cHi[a]);
+                    const float ext = cHi[a] - cLo[a];
+                    use[a] = (ext > 0.0f) && (ext < __builtin_inff());
+                    scale[a] = use[a] ? (float)kBins / ext : 0.0f;
+                }
+                for (uint32_t i = lane; i < 3u * kBins; i += 64u) {
+                    const uint32_t a = i / kBins, k = i % kBins;
+                    for (int d = 0; d < 3; ++d) { binLo[a][k][d] = orderedKey(__builtin_inff()); binHi[a][k][d] = orderedKey(-__builtin_inff()); }
+                    binCnt[a][k] = 0u;
+                }
+                __syncthreads();
+                for (uint32_t i = cur.b + lane; i < cur.e; i += 64u) {
+                    const uint32_t j = idx[i];
+                    uint32_t kl[3], kh[3];
+                    for (int d = 0; d < 3; ++d) { kl[d] = orderedKey(bl[d][j]); kh[d] = orderedKey(bh[d][j]); }
+                    for (int a = 0; a < 3; ++a) {
+                        if (!use[a]) continue;
+                        const float pc = 0.5f * bl[a][j] + 0.5f * bh[a][j];
+                        int k = (int)((pc - cLo[a]) * scale[a]);
+                        k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                        for (int d = 0; d < 3; ++d) { atomicMin(&binLo[a][k][d], kl[d]); atomicMax(&binHi[a][k][d], kh[d]); }
+                        atomicAdd(&binCnt[a][k], 1u);
+                    }
+                }
+                __syncthreads();
+                // candidate plane (a, k): bins [0, k) left, [k, kBins) right
+                float cost = __builtin_inff();
+                uint32_t leftCnt = 0;
+                if (lane < 45u) {
+                    const int a = (int)lane / 15, k = (int)lane % 15 + 1;
+                    if (use[a]) {
+                        float aLo[3] = { __builtin_inff(), __builtin_inff(), __builtin_inff() }, aHi[3] = { -__builtin_inff(), -__builtin_inff(), -__builtin_inff() };
+                        float rLo[3] = { __builtin_inff(), __builtin_inff(), __builtin_inff() }, rHi[3] = { -__builtin_inff(), -__builtin_inff(), -__builtin_inff() };
+                        uint32_t c = 0, rc = 0;
+                        for (int q = 0; q < kBins; ++q) {
+                            const uint32_t n = binCnt[a][q];
+                            if (q < k) { c += n; for (int d = 0; d < 3; ++d) { aLo[d] = fminf(aLo[d], fromOrderedKey(binLo[a][q][d])); aHi[d] = fmaxf(aHi[d], fromOrderedKey(binHi[a][q][d])); } }
+                            else { rc += n; for (int d = 0; d < 3; ++d) { rLo[d] = fminf(rLo[d], fromOrderedKey(binLo[a][q][d])); rHi[d] = fmaxf(rHi[d], fromOrderedKey(binHi[a][q][d])); } }
+                        }
+                        if (c != 0 && rc != 0) { cost = boxHalfArea(aLo, aHi) * (float)c + boxHalfArea(rLo, rHi) * (float)rc; leftCnt = c; }
+                    }
+                }
+                const float best = waveMinF(cost);
+                const uint64_t who = __ballot(cost == best && cost < __builtin_inff());
+                if (who != 0) {
+                    const int w = __builtin_ctzll(who);                 // the earliest (axis, plane) among the cheapest
+                    const int bestAxis = w / 15, bestSplit = w % 15 + 1;
+                    const uint32_t nLeft = (uint32_t)__shfl((int)leftCnt, w);
+                    const float bLo = cLo[bestAxis], bScale = scale[bestAxis];
+                    uint32_t lp = cur.b, rp = cur.b + nLeft;
+                    for (uint32_t base = cur.b; base < cur.e; base += 64u) {
+                        const uint32_t i = base + lane;
+                        bool in = i < cur.e, goLeft = false;
+                        uint32_t j = 0;
+                        if (in) {
+                            j = idx[i];
+                            const float pc = 0.5f * bl[bestAxis][j] + 0.5f * bh[bestAxis][j];
+                            int k = (int)((pc - bLo) * bScale);
+                            k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                            goLeft = k < bestSplit;
+                        }
+                        const uint64_t lm = __ballot(in && goLeft), rm = __ballot(in && !goLeft);
+                        const uint64_t below = (1ull << lane) - 1ull;
+                        if (in) tmp[goLeft ? lp + (uint32_t)__popcll(lm & below) : rp + (uint32_t)__popcll(rm & below)] = j;
+                        lp += (uint32_t)__popcll(lm);
+                        rp += (uint32_t)__popcll(rm);
+                    }
+                    __syncthreads();
+                    for (uint32_t i = cur.b + lane; i < cur.e; i += 64u) idx[i] = tmp[i];
+                    __syncthreads();
+                    mid = cur.b + nLeft;
+                }
+            }
+            const uint32_t nl = mid - cur.b, nr = cur.e - mid;
+            const uint32_t childL = nl == 1u ? nLeaves - 1u + f + cur.b : nextId++;
+            const uint32_t childR = nr == 1u ? nLeaves - 1u + f + mid : nextId++;
+            if (lane == 0) {
+                left[cur.node] = childL;
+                right[cur.node] = childR;
+                parent[childL] = cur.node;
+                parent[childR] = cur.node;
+            }
+            const Todo tl{ childL, cur.b, mid }, tr{ childR, mid, cur.e };
+            const bool leftFirst = nl <= nr;
+            const Todo first = leftFirst ? tl : tr, second = leftFirst ? tr : tl;
+            const uint32_t nFirst = leftFirst ? nl : nr, nSecond = leftFirst ? nr : nl;
+            if (nSecond >= 2u && nFirst >= 2u) { stack[sp++] = second; cur = first; continue; }
+            if (nFirst >= 2u) { cur = first; continue; }
+            if (nSecond >= 2u) { cur = second; continue; }
+            if (sp == 0) break;
+            cur = stack[--sp];
+        }
+        for (uint32_t i = lane; i < size; i += 64u) sortedIds[f + i] = ids[idx[i]];
+    }
+}
+
 // depth of the children of every internal node at depth `level`; *any = 1 if there was such a node
 __global__ void __launch_bounds__(256) assignLevel(const uint32_t* __restrict__ left, const uint32_t* __restrict__ right, uint32_t nInternal,
                                                    uint32_t* __restrict__ depth, uint32_t level, uint32_t* __restrict__ any)
@@ -784,6 +943,13 @@ int DeviceWideBuilder::topology(const float* verts, size_t nVerts, const int32_t
             hipLaunchKernelGGL(treeletRoots, dim3(blocks(nInternal)), dim3(256), 0, nullptr, rangeLo, rangeHi, parent, (uint32_t)nInternal, treelet, roots, dAny + 32);
             // one thread per root: the count stays on the device, the grid covers the most there can be
             const size_t maxRoots = nInternal / 2 + 1;
+            const char* oneThread = std::getenv("YART_DEVICE_TREELET_THREAD");
+            if (treelet <= (uint32_t)kWaveTreelet && !(oneThread && oneThread[0] == '1')) {
+                // one wave per root, the waves of a fixed grid taking roots in turn (the count stays on the device)
+                const size_t want = maxRoots < 65536 ? maxRoots : 65536;
+                hipLaunchKernelGGL(treeletSahWave, dim3(static_cast<uint32_t>(want)), dim3(64), 0, nullptr, roots, dAny + 32, rangeLo, rangeHi, (uint32_t)n,
+                                   const_cast<uint32_t*>(sortedIds), primLo, primHi, left, right, parent);
+            } else
             hipLaunchKernelGGL(treeletSah, dim3(static_cast<uint32_t>((maxRoots + 63) / 64)), dim3(64), 0, nullptr, roots, dAny + 32, rangeLo, rangeHi, (uint32_t)n,
                                const_cast<uint32_t*>(sortedIds), primLo, primHi, left, right, parent);
             YART_HIP(hipGetLastError());
