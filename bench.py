@@ -168,6 +168,25 @@ def main():
     any_consistent = bool(np.array_equal(d_occ.cpu().numpy() != 0, a["prim"] != -1))
     hit_frac = float((a["prim"] != -1).mean())
     del plain, d_occ, counted_hits
+    # ---- any-hit rates (also any-hit Mrays/s; maxT = inf as above and maxT in U(0, 0.5)), outside the timed region
+    any_hit = None
+    if world == 1 and not strong:
+        any_hit = {}
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(11)
+        d_short = d_rays.clone()
+        d_short[:, 7] = torch.rand(args.rays, device="cuda", generator=gen) * 0.5
+        for name, batch in (("maxT_inf", d_rays), ("maxT_U(0,0.5)", d_short)):
+            d_o = acc.intersect_any(batch, flags)
+            torch.cuda.synchronize()
+            t_any = time.perf_counter()
+            for _ in range(args.steps):
+                d_o = acc.intersect_any(batch, flags, out=d_o)
+            torch.cuda.synchronize()
+            t_any = (time.perf_counter() - t_any) / args.steps
+            any_hit[name] = {"Mrays_s": round(args.rays / t_any / 1e6, 1), "ms_per_step": round(t_any * 1e3, 3),
+                             "occluded_fraction": round(float((d_o != 0).float().mean().item()), 4)}
+        del d_short, d_o
 
     value = total_rays * args.steps / elapsed / 1e6
     out = {
@@ -268,6 +287,8 @@ def main():
                                if achieved is not None else
                                "no PMC traffic figure for this configuration in profiles/traffic.json: HBM-side rate not available; "
                                "algorithmic_GBps counts every fetch, cached or not")
+    if any_hit is not None:
+        out["any_hit"] = any_hit
     out["parity_gate"] = {"idempotent_and_counting_variant_equal": same_as_counted,
                           "sorted_persistent_equals_unsorted_static": order_independent,
                           "any_hit_consistent_with_closest": any_consistent}

@@ -59,6 +59,46 @@ __global__ __launch_bounds__(256) void surfaceKernel(const float4* __restrict__ 
 
 } // namespace
 
+// The surface rows from the scene arrays on the device (yart_accel_set_surface_data for device-built accels: the host loop
+// took 0.17 s for 10 M triangles).  include/triangle.h:158-164, include/vector.h:165-168 with hipcc's correctly rounded
+// `/` and sqrtf under -ffp-contract=off: the host loop's bits.  *bad is set when a vertex index is out of range.
+__global__ void __launch_bounds__(256) surfaceRowsKernel(const float* __restrict__ verts, uint32_t nVerts, const int32_t* __restrict__ tris,
+                                                         uint32_t nTris, const float* __restrict__ normals,
+                                                         const uint32_t* __restrict__ slotOfInput, float4* __restrict__ rows,
+                                                         uint32_t* __restrict__ bad)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nTris) return;
+    const int32_t* t = tris + (size_t)i * 5;
+    const int32_t i0 = t[0], i1 = t[1], i2 = t[2];
+    if (i0 < 0 || i1 < 0 || i2 < 0 || (uint32_t)i0 >= nVerts || (uint32_t)i1 >= nVerts || (uint32_t)i2 >= nVerts) { *bad = 1u; return; }
+    const float* p0 = verts + (size_t)i0 * 3;
+    const float* p1 = verts + (size_t)i1 * 3;
+    const float* p2 = verts + (size_t)i2 * 3;
+    const float e1x = p1[0] - p0[0], e1y = p1[1] - p0[1], e1z = p1[2] - p0[2];
+    const float e2x = p2[0] - p0[0], e2y = p2[1] - p0[1], e2z = p2[2] - p0[2];
+    const float cx = e1y * e2z - e1z * e2y;
+    const float cy = e1z * e2x - e1x * e2z;
+    const float cz = e1x * e2y - e1y * e2x;
+    const float inv = 1.0f / sqrtf(cx * cx + cy * cy + cz * cz);
+    const float* n0 = normals + (size_t)i0 * 3;
+    const float* n1 = normals + (size_t)i1 * 3;
+    const float* n2 = normals + (size_t)i2 * 3;
+    float4* r = rows + (size_t)slotOfInput[i] * 4;
+    r[0] = make_float4(cx * inv, cy * inv, cz * inv, n0[0]);
+    r[1] = make_float4(n0[1], n0[2], n1[0], n1[1]);
+    r[2] = make_float4(n1[2], n2[0], n2[1], n2[2]);
+    r[3] = make_float4(__int_as_float(t[3]), __int_as_float(t[4]), 0.0f, 0.0f);
+}
+
+hipError_t launchSurfaceRows(const float* verts, uint32_t nVerts, const int32_t* tris, uint32_t nTris, const float* normals,
+                             const uint32_t* slotOfInput, void* rows, uint32_t* bad, hipStream_t stream)
+{
+    if (nTris == 0) return hipSuccess;
+    surfaceRowsKernel<<<(nTris + 255) / 256, 256, 0, stream>>>(verts, nVerts, tris, nTris, normals, slotOfInput, static_cast<float4*>(rows), bad);
+    return hipGetLastError();
+}
+
 hipError_t launchSurface(const void* rays, const void* hits, uint32_t n, const void* rows,
                          const void* spheres, void* out, hipStream_t stream)
 {
