@@ -118,7 +118,7 @@ def main():
     d_rays = torch.from_numpy(rays).cuda()
     d_hits = torch.empty((args.rays, 4), dtype=torch.float32, device="cuda")
     flags = 0
-    if not args.no_sort:
+    if not args.no_sort and not strong:       # strong: the slice arrives in the coherence order already (ordered once, above)
         flags |= api.YART_SORT_RAYS
     if args.static:
         flags |= api.YART_STATIC_LAUNCH
@@ -208,7 +208,7 @@ def main():
                                                              "in ONE batch cut into contiguous slices of the coherence order, one per GPU" if strong else "per GPU",
                                                              "reference binary (sphere pass + triangle pass)" if args.reference_tree
                                                              else "4-wide quantised, triangles+spheres",
-                                                             "off" if args.no_sort else "morton+octant",
+                                                             "off" if args.no_sort else ("none per call: the batch was ordered once by morton+octant" if strong else "morton+octant"),
                                                              "static" if args.static else "persistent"),
             "rays_per_gpu": args.rays, "tris": args.tris, "spheres": args.spheres,
             "scene_replicated": True, "hit_fraction": round(hit_frac, 4),
