@@ -23,8 +23,9 @@ extern "C" {
 /* ---- records --------------------------------------------------------- */
 
 /* Ray, 32 bytes: the reference's `struct Ray` (include/vector.h:238-250).
- * dir must be unit length (the reference's sphere test assumes it,
- * include/sphere.h:67-68). */
+ * dir must be unit length, as a direction normalised in fp32 is (| |dir|^2 - 1 | <= 7 * 2^-24): the reference's sphere
+ * test assumes it (include/sphere.h:67-68), and the engine's sphere boxes are sized for what that test accepts from
+ * such a direction.  Triangle results do not depend on the length of dir. */
 typedef struct YartRay {
     float ox, oy, oz, tmin;
     float dx, dy, dz, tmax;
