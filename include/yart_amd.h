@@ -361,7 +361,7 @@ typedef struct YartWavefrontIter {   /* one iteration = one bounce of every path
     uint64_t closest_rays;      /* live paths traced by the closest-hit batch */
     uint64_t shadow_rays;       /* of them hit a surface and sent a shadow ray */
     float ms_closest;           /* closest-hit batch (sort + traversal), HIP events on the stream */
-    float ms_surface;           /* yart_surface_dev */
+    float ms_surface;           /* 0 since the surface step became part of the shade kernel (kept for layout) */
     float ms_shadow;            /* any-hit batch */
     float ms_shade;             /* generate + shade + apply kernels */
 } YartWavefrontIter;
@@ -373,7 +373,7 @@ typedef struct YartWavefrontStats {
 } YartWavefrontStats;
 
 /* slots: paths in flight (>= 1; 2^20 .. 2^23 fills the GPU).  The accel must have its surface data
- * (yart_accel_set_surface_data).  HBM: 224 bytes per slot + 16 bytes per path of a sample slab. */
+ * (yart_accel_set_surface_data).  HBM: 176 bytes per slot + 16 bytes per path of a sample slab. */
 int yart_wavefront_create(YartAccel* accel, size_t slots, YartWavefront** out);
 void yart_wavefront_destroy(YartWavefront* wf);
 /* Renders job->spp samples of every listed pixel into d_rgb (device, 3 floats per listed pixel, in

@@ -13,6 +13,7 @@
 
 #include "../../include/yart_amd.h"
 #include "traverse.h"
+#include "surface_inl.h"
 
 namespace yart {
 namespace {
@@ -25,33 +26,9 @@ __global__ __launch_bounds__(256) void surfaceKernel(const float4* __restrict__ 
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 h = hits[i];
-    const int prim = __float_as_int(h.w);
-    float nx = 0.0f, ny = 0.0f, nz = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
-    int meshIdx = -1, triIdx = -1;
-    if (prim >= 0) {
-        const float4 r0 = rows[static_cast<size_t>(prim) * 4 + 0];     // geometric normal, n0.x
-        const float4 r1 = rows[static_cast<size_t>(prim) * 4 + 1];     // n0.yz, n1.xy
-        const float4 r2 = rows[static_cast<size_t>(prim) * 4 + 2];     // n1.z, n2.xyz
-        const float4 r3 = rows[static_cast<size_t>(prim) * 4 + 3];     // meshIdx, triIdx
-        meshIdx = __float_as_int(r3.x);
-        triIdx = __float_as_int(r3.y);
-        nx = r0.x; ny = r0.y; nz = r0.z;
-        const float u = h.y, v = h.z;
-        const float w = 1.0f - u - v;                                   // include/triangle.h:168
-        sx = r0.w * w + r1.z * u + r2.y * v;
-        sy = r1.x * w + r1.w * u + r2.z * v;
-        sz = r1.y * w + r2.x * u + r2.w * v;
-    } else if (prim <= -2) {
-        const float4 o = rays[static_cast<size_t>(i) * 2], d = rays[static_cast<size_t>(i) * 2 + 1];
-        const float4 s = spheres[-(prim + 2)];
-        const float t = h.x;
-        const float x = o.x + d.x * t - s.x, y = o.y + d.y * t - s.y, z = o.z + d.z * t - s.z;  // include/sphere.h:80
-        const float inv = 1.0f / sqrtf(x * x + y * y + z * z);       // include/vector.h:165-168; hipcc's default
-        // sqrtf and '/' are the correctly rounded ones (__fsqrt_rn is the NATIVE approximation here)
-        nx = x * inv; ny = y * inv; nz = z * inv;
-        sx = nx; sy = ny; sz = nz;
-        triIdx = -(prim + 2);
-    }
+    const SurfacePoint sp = surfaceOfHit(h, rows, spheres, rays + static_cast<size_t>(i) * 2);
+    const float nx = sp.nx, ny = sp.ny, nz = sp.nz, sx = sp.sx, sy = sp.sy, sz = sp.sz;
+    const int meshIdx = sp.meshIdx, triIdx = sp.triIdx;
     out[static_cast<size_t>(i) * 3 + 0] = make_float4(nx, ny, nz, h.x);
     out[static_cast<size_t>(i) * 3 + 1] = make_float4(sx, sy, sz, h.y);
     out[static_cast<size_t>(i) * 3 + 2] = make_float4(h.z, h.w, __int_as_float(meshIdx), __int_as_float(triIdx));

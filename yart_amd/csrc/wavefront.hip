@@ -8,7 +8,8 @@
 //
 //   generate   free slots take the next path numbers from a counter and get their camera ray
 //              (src/renderer.cpp:43-50, include/camera.h:24-31)
-//   shade      hit -> light sample, shadow ray, roulette, cosine-weighted bounce  (:59-102, :113-129)
+//   shade      hit -> normal and shading normal (surface_inl.h, the step yart_surface_dev does for other callers),
+//              light sample, shadow ray, roulette, cosine-weighted bounce  (:59-102, :113-129)
 //   apply      occlusion -> direct light added; finished paths write colour / spp   (:104-110, :132)
 //
 // A slot without a path carries a ray that misses the scene's bounds, so batches are always `slots`
@@ -27,6 +28,7 @@
 
 #include "../../include/yart_amd.h"
 #include "accel.h"
+#include "surface_inl.h"
 
 namespace yart {
 namespace {
@@ -39,7 +41,6 @@ constexpr size_t kSlabBytes = size_t(2) << 30;     // per-path results of one sa
 struct WfBuffers {
     float4* rays;        // 2 per slot: pending closest-hit ray (YartRay)
     float4* hits;        // 1 per slot (YartHit)
-    float4* surf;        // 3 per slot (YartSurface)
     float4* shadow;      // 2 per slot
     uint8_t* occ;        // 1 per slot
     uint32_t* path;      // slab path number, or kNoPath
@@ -158,7 +159,11 @@ __global__ void __launch_bounds__(256) wfGenerate(WfBuffers B, DiffuseParams J, 
     }
 }
 
-__global__ void __launch_bounds__(256) wfShade(WfBuffers B, DiffuseParams J, uint32_t nSlots, float4* slab)
+// Hit post-processing (row K) is folded in: the surface point comes straight from the hit record and the accel's surface
+// rows (surface_inl.h) instead of a YartSurface record written by one kernel and read by the next (96 bytes per slot
+// and iteration less; round 3).
+__global__ void __launch_bounds__(256) wfShade(WfBuffers B, DiffuseParams J, uint32_t nSlots, float4* slab,
+                                               const float4* __restrict__ surfRows, const float4* __restrict__ surfSpheres)
 {
     __shared__ uint32_t lds[4];
     uint32_t nLive = 0, nShadow = 0, nMissed = 0;
@@ -167,9 +172,8 @@ __global__ void __launch_bounds__(256) wfShade(WfBuffers B, DiffuseParams J, uin
     if (live) {
         ++nLive;
         const uint32_t p = B.path[i];
-        const float4 s0 = B.surf[(size_t)i * 3 + 0];          // normal, t
-        const float4 s2 = B.surf[(size_t)i * 3 + 2];          // v, prim, meshIdx, triIdx
-        const int prim = __float_as_int(s2.y);
+        const float4 hit = B.hits[i];                          // t, u, v, prim
+        const int prim = __float_as_int(hit.w);
         if (prim == -1) {
             // src/renderer.cpp:59-60: nothing hit, the sample is what it has gathered so far
             const float4 c = B.color[i];
@@ -187,12 +191,14 @@ __global__ void __launch_bounds__(256) wfShade(WfBuffers B, DiffuseParams J, uin
             const uint32_t pixel = J.pixels ? J.pixels[pixelIdx] : pixelIdx;
             const uint32_t key = pathKey(J.seed, pixel, J.slabFirstSample + p % J.slabSamples);
             const uint32_t dim = 2u + (uint32_t)bounce * 32u;
+            const SurfacePoint sp = surfaceOfHit(hit, surfRows, surfSpheres, B.rays + (size_t)i * 2);
+            const float4 s0 = make_float4(sp.nx, sp.ny, sp.nz, hit.x);           // normal, t
+            const float4 s1 = make_float4(sp.sx, sp.sy, sp.sz, hit.y);           // shading normal, u
             const float t = s0.w;
             const float Px = o.x + d.x * t, Py = o.y + d.y * t, Pz = o.z + d.z * t;            // :72
             const bool front = s0.x * d.x + s0.y * d.y + s0.z * d.z < 0.0f;                      // :74
             // :73-74: nl is the SHADING normal (not normalised, include/triangle.h:166-171), turned by the sign of the
             // geometric one.  A scene given without vertex normals (all zero) is flat shaded: the geometric normal.
-            const float4 s1 = B.surf[(size_t)i * 3 + 1];          // shading normal, u
             const bool flat = s1.x == 0.0f && s1.y == 0.0f && s1.z == 0.0f;
             const float snx = flat ? s0.x : s1.x, sny = flat ? s0.y : s1.y, snz = flat ? s0.z : s1.z;
             const float nlx = front ? snx : -snx, nly = front ? sny : -sny, nlz = front ? snz : -snz;
@@ -311,6 +317,7 @@ struct YartWavefront {
     float4* slab = nullptr;
     size_t slabPaths = 0;
     std::vector<hipEvent_t> events;
+    uint32_t* hostCounters = nullptr;   // pinned: two copies of the counter block, read back while the next iteration runs
 };
 
 namespace {
@@ -351,7 +358,7 @@ int yart_wavefront_create(YartAccel* accel, size_t slots, YartWavefront** out)
     w->accel = accel;
     w->slots = slots;
     const size_t n = slots;
-    const size_t sizes[10] = { n * 32, n * 16, n * 48, n * 32, n, n * 4, n * 16, n * 16, n * 16, 512 };
+    const size_t sizes[9] = { n * 32, n * 16, n * 32, n, n * 4, n * 16, n * 16, n * 16, 512 };
     size_t total = 0;
     for (size_t s : sizes) total += alignUp(s);
     hipError_t e = hipMalloc(&w->block, total);
@@ -360,14 +367,13 @@ int yart_wavefront_create(YartAccel* accel, size_t slots, YartWavefront** out)
     auto take = [&](size_t bytes) { char* q = p; p += alignUp(bytes); return q; };
     w->buf.rays = reinterpret_cast<float4*>(take(sizes[0]));
     w->buf.hits = reinterpret_cast<float4*>(take(sizes[1]));
-    w->buf.surf = reinterpret_cast<float4*>(take(sizes[2]));
-    w->buf.shadow = reinterpret_cast<float4*>(take(sizes[3]));
-    w->buf.occ = reinterpret_cast<uint8_t*>(take(sizes[4]));
-    w->buf.path = reinterpret_cast<uint32_t*>(take(sizes[5]));
-    w->buf.weight = reinterpret_cast<float4*>(take(sizes[6]));
-    w->buf.color = reinterpret_cast<float4*>(take(sizes[7]));
-    w->buf.pend = reinterpret_cast<float4*>(take(sizes[8]));
-    w->buf.counters = reinterpret_cast<uint32_t*>(take(sizes[9]));
+    w->buf.shadow = reinterpret_cast<float4*>(take(sizes[2]));
+    w->buf.occ = reinterpret_cast<uint8_t*>(take(sizes[3]));
+    w->buf.path = reinterpret_cast<uint32_t*>(take(sizes[4]));
+    w->buf.weight = reinterpret_cast<float4*>(take(sizes[5]));
+    w->buf.color = reinterpret_cast<float4*>(take(sizes[6]));
+    w->buf.pend = reinterpret_cast<float4*>(take(sizes[7]));
+    w->buf.counters = reinterpret_cast<uint32_t*>(take(sizes[8]));
     *out = w;
     return YART_OK;
 }
@@ -380,6 +386,7 @@ void yart_wavefront_destroy(YartWavefront* w)
         (void)hipFree(w->block);
         (void)hipFree(w->slab);
         for (hipEvent_t ev : w->events) (void)hipEventDestroy(ev);
+        (void)hipHostFree(w->hostCounters);
     }
     delete w;
 }
@@ -411,7 +418,11 @@ int yart_wavefront_render_diffuse(YartWavefront* w, const YartDiffuseJob* job, f
         if (e != hipSuccess) return failStatus(YART_ERR_OUT_OF_MEMORY, std::string("hipMalloc(sample slab): ") + hipGetErrorString(e));
         w->slabPaths = slabPathsMax;
     }
-    while (w->events.size() < 6) {
+    if (!w->hostCounters) {
+        const hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&w->hostCounters), 2 * 4 * kCtr * sizeof(uint32_t));
+        if (e != hipSuccess) { w->hostCounters = nullptr; return hipFail(e, "hipHostMalloc"); }
+    }
+    while (w->events.size() < 16) {
         hipEvent_t ev;
         const hipError_t e = hipEventCreate(&ev);
         if (e != hipSuccess) return hipFail(e, "hipEventCreate");
@@ -438,7 +449,6 @@ int yart_wavefront_render_diffuse(YartWavefront* w, const YartDiffuseJob* job, f
     const YartRay* dRays = reinterpret_cast<const YartRay*>(w->buf.rays);
     const YartRay* dShadow = reinterpret_cast<const YartRay*>(w->buf.shadow);
     YartHit* dHits = reinterpret_cast<YartHit*>(w->buf.hits);
-    YartSurface* dSurf = reinterpret_cast<YartSurface*>(w->buf.surf);
     hipError_t e = hipSuccess;
     int status = YART_OK;
     size_t iterNo = 0;
@@ -453,33 +463,39 @@ int yart_wavefront_render_diffuse(YartWavefront* w, const YartDiffuseJob* job, f
         uint32_t finished = 0, handedOut = 0;
         // every iteration ends at least one bounce of every live path, and a path has at most max_depth
         const size_t guardIters = ((size_t)J.slabPaths / nSlots + 2) * ((size_t)job->max_depth + 1) + 8;
-        for (size_t it = 0; finished < J.slabPaths; ++it) {
-            if (it > guardIters) return failStatus(YART_ERR_HIP, "yart_wavefront_render_diffuse: paths did not finish (internal error)");
-            const bool generate = job->regenerate ? true : (finished == handedOut);      // pool mode: only when every slot is free
-            (void)hipEventRecord(w->events[0], stream);
+        // One iteration's launches; its counters are copied to pinned copy `k` and event 7 of set `k` marks the end.
+        auto enqueue = [&](int k, bool generate) -> int {
+            hipEvent_t* ev = w->events.data() + 8 * k;
+            (void)hipEventRecord(ev[0], stream);
             if (generate) {
                 hipLaunchKernelGGL(wfGenerate, dim3(grid), dim3(256), 0, stream, w->buf, J, nSlots, perBlock);
                 if ((e = hipGetLastError()) != hipSuccess) return hipFail(e, "wfGenerate");
             }
             if ((e = hipMemsetAsync(w->buf.counters + 2 * kCtr, 0, 2 * kCtr * 4, stream)) != hipSuccess) return hipFail(e, "hipMemsetAsync");
-            (void)hipEventRecord(w->events[1], stream);
-            status = yart_intersect_closest_dev(w->accel, dRays, nSlots, dHits, job->flags, stream);
-            if (status != YART_OK) return status;
-            (void)hipEventRecord(w->events[2], stream);
-            status = yart_surface_dev(w->accel, dRays, dHits, nSlots, dSurf, stream);
-            if (status != YART_OK) return status;
-            (void)hipEventRecord(w->events[3], stream);
-            hipLaunchKernelGGL(wfShade, dim3(grid), dim3(256), 0, stream, w->buf, J, nSlots, w->slab);
+            (void)hipEventRecord(ev[1], stream);
+            int stt = yart_intersect_closest_dev(w->accel, dRays, nSlots, dHits, job->flags, stream);
+            if (stt != YART_OK) return stt;
+            (void)hipEventRecord(ev[2], stream);           // (the surface step is part of the shade kernel)
+            hipLaunchKernelGGL(wfShade, dim3(grid), dim3(256), 0, stream, w->buf, J, nSlots, w->slab,
+                               static_cast<const float4*>(w->accel->dSurfRows), static_cast<const float4*>(w->accel->dSurfSpheres));
             if ((e = hipGetLastError()) != hipSuccess) return hipFail(e, "wfShade");
-            (void)hipEventRecord(w->events[4], stream);
-            status = yart_intersect_any_dev(w->accel, dShadow, nSlots, w->buf.occ, job->flags, stream);
-            if (status != YART_OK) return status;
-            (void)hipEventRecord(w->events[5], stream);
+            (void)hipEventRecord(ev[3], stream);
+            stt = yart_intersect_any_dev(w->accel, dShadow, nSlots, w->buf.occ, job->flags, stream);
+            if (stt != YART_OK) return stt;
+            (void)hipEventRecord(ev[4], stream);
             hipLaunchKernelGGL(wfApply, dim3(grid), dim3(256), 0, stream, w->buf, J, nSlots, w->slab);
             if ((e = hipGetLastError()) != hipSuccess) return hipFail(e, "wfApply");
-            uint32_t raw[4 * kCtr];
-            if ((e = hipMemcpyAsync(raw, w->buf.counters, sizeof raw, hipMemcpyDeviceToHost, stream)) != hipSuccess) return hipFail(e, "hipMemcpyAsync");
-            if ((e = hipStreamSynchronize(stream)) != hipSuccess) return hipFail(e, "hipStreamSynchronize");
+            (void)hipEventRecord(ev[5], stream);
+            if ((e = hipMemcpyAsync(w->hostCounters + (size_t)k * 4 * kCtr, w->buf.counters, 4 * kCtr * sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess)
+                return hipFail(e, "hipMemcpyAsync");
+            (void)hipEventRecord(ev[7], stream);
+            return YART_OK;
+        };
+        // waits for iteration copy `k` and books it
+        auto collect = [&](int k) -> int {
+            hipEvent_t* ev = w->events.data() + 8 * k;
+            if ((e = hipEventSynchronize(ev[7])) != hipSuccess) return hipFail(e, "hipEventSynchronize");
+            const uint32_t* raw = w->hostCounters + (size_t)k * 4 * kCtr;
             const uint32_t c[4] = { raw[0], raw[kCtr], raw[2 * kCtr], raw[3 * kCtr] };
             handedOut = std::min<uint32_t>(c[0], J.slabPaths);
             const uint32_t live = c[2], senders = c[3];
@@ -487,15 +503,38 @@ int yart_wavefront_render_diffuse(YartWavefront* w, const YartDiffuseJob* job, f
             st.shadow_rays += senders;
             finished = c[1];
             float ms[5] = { 0, 0, 0, 0, 0 };
-            for (int k = 0; k < 5; ++k) (void)hipEventElapsedTime(&ms[k], w->events[k], w->events[k + 1]);
-            st.ms_closest += ms[1]; st.ms_surface += ms[2]; st.ms_shadow += ms[4]; st.ms_shade += ms[0] + ms[3];
+            for (int q = 0; q < 5; ++q) (void)hipEventElapsedTime(&ms[q], ev[q], ev[q + 1]);
+            st.ms_closest += ms[1]; st.ms_shadow += ms[3]; st.ms_shade += ms[0] + ms[2] + ms[4];
             if (iters && iterNo < max_iters) {
                 YartWavefrontIter& r = iters[iterNo];
                 r.closest_rays = live; r.shadow_rays = senders;
-                r.ms_closest = ms[1]; r.ms_surface = ms[2]; r.ms_shadow = ms[4]; r.ms_shade = ms[0] + ms[3];
+                r.ms_closest = ms[1]; r.ms_surface = 0.0f; r.ms_shadow = ms[3]; r.ms_shade = ms[0] + ms[2] + ms[4];
             }
             ++iterNo;
             ++st.iterations;
+            return YART_OK;
+        };
+        if (job->regenerate) {
+            // Free slots take new paths in every iteration, so nothing an iteration does depends on the host having seen
+            // the counters of the one before: iteration it + 1 is enqueued before the host waits for iteration it, and the
+            // GPU never idles over the read-back.  The iteration enqueued after the last paths ended finds every slot
+            // free and no path left: its rays are the fillers, it changes nothing and is not booked.
+            if ((status = enqueue(0, true)) != YART_OK) return status;
+            for (size_t it = 0;; ++it) {
+                if (it > guardIters) return failStatus(YART_ERR_HIP, "yart_wavefront_render_diffuse: paths did not finish (internal error)");
+                if ((status = enqueue((int)((it + 1) & 1), true)) != YART_OK) return status;
+                if ((status = collect((int)(it & 1))) != YART_OK) return status;
+                if (finished >= J.slabPaths) {
+                    if ((e = hipEventSynchronize(w->events[8 * ((it + 1) & 1) + 7])) != hipSuccess) return hipFail(e, "hipEventSynchronize");
+                    break;
+                }
+            }
+        } else {
+            for (size_t it = 0; finished < J.slabPaths; ++it) {
+                if (it > guardIters) return failStatus(YART_ERR_HIP, "yart_wavefront_render_diffuse: paths did not finish (internal error)");
+                if ((status = enqueue(0, finished == handedOut)) != YART_OK) return status;      // pool mode: only when every slot is free
+                if ((status = collect(0)) != YART_OK) return status;
+            }
         }
         st.paths += J.slabPaths;
         hipLaunchKernelGGL(wfReduce, dim3(((uint32_t)nPixels + 255u) / 256u), dim3(256), 0, stream, w->slab, (uint32_t)nPixels, ss, d_rgb,
