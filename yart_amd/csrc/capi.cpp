@@ -245,7 +245,7 @@ int runIntersect(YartAccel* a, const Launch& L, const CallScratch* given)
             ScopedSpan span(a, 2, L.stream, !given);
             e = yart::launchTraceWide(W, L.any, L.count, persistent, a->numCUs, L.stream);
         }
-        // rays the wide kernel does not take (irregular, outside the cover, tied across reference leaves) are answered on
+        // rays the wide kernel does not take (irregular, outside the cover, too nearly axis-parallel for the box arithmetic) are answered on
         // the reference tree
         P.deferFlag = W.deferFlag;
         P.deferList = W.deferList;
@@ -625,7 +625,7 @@ static int pooledHostCall(YartAccel* accel, const YartRay* rays, size_t n, YartH
         const char* hOut = static_cast<char*>(c.host) + kStagingRays * sizeof(YartRay);
         // a handful of rays cannot fill persistent workgroups: plain grid.  The default kernel alone first (no fix-up
         // launches: one-ray calls are launch bound); the block is host memory, so whether it left a ray unresolved
-        // (irregular, outside the cover, tied across reference leaves) shows in the results, and only then is the
+        // (irregular, outside the cover, too nearly axis-parallel for the box arithmetic) shows in the results, and only then is the
         // batch traced again on the reference's tree.
         const bool wideOnly = !(flags & (YART_REFERENCE_RULE | YART_REFERENCE_TREE)) && accel->hasWide;
         for (int pass = 0; pass < 2 && st == YART_OK; ++pass) {

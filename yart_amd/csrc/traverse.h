@@ -32,8 +32,8 @@ struct TraceParams {
     float sceneLo[3], sceneHi[3];   // bounds of the scene (for that pad)
 };
 
-// What the wide kernel leaves in the output of a ray it does not answer (irregular, outside the cover, an exact-t tie across
-// two leaves of the reference's tree) until the fix-up launches overwrite it; the fix-up sphere pass keeps the ray marked
+// What the wide kernel leaves in the output of a ray it does not answer (irregular, outside the cover, too nearly
+// axis-parallel for the box arithmetic) until the fix-up launches overwrite it; the fix-up sphere pass keeps the ray marked
 // for the triangle pass (kUnresolvedV in YartHit.v / kUnresolvedOcc).  include/yart_amd.h: YART_PRIM_UNRESOLVED.
 constexpr int32_t kUnresolvedPrim = INT32_MIN;
 constexpr uint8_t kUnresolvedOcc = 2;
