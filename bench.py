@@ -366,6 +366,7 @@ def gather_check(rank, world, device):
     import torch.distributed as dist
     from yart_amd import api, scenes
     try:
+        torch.cuda.set_device(device)              # the current device is per thread, and this runs in a thread of its own
         W, H = 640, 360
         v, t, s = scenes.architectural(40000, seed=2)
         acc = api.Accel(v, t, s, device=device)
