@@ -35,6 +35,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cstdio>
+#include <mutex>
 
 #include "traverse.h"
 #include "wide_build.h"
@@ -947,21 +948,30 @@ hipError_t launchPool(const WideParams& P, int numCUs, hipStream_t stream)
     const size_t lds = ((size_t)PF_COUNT * NS + 256 + (size_t)P.poolWindow * NS) * 4;
     const int perCU = (int)(163840 / lds) < 1 ? 1 : (int)(163840 / lds);
     const uint32_t grid = (uint32_t)numCUs * (uint32_t)perCU;
-    // experiment: one overflow area per device, sized for the largest launch so far; launches of this kernel must not overlap
+    // Experiment: one overflow area per device, sized for the largest launch so far, shared by every launch of this kernel
+    // on the device.  So that callers on several threads or streams cannot collide in it, the host side is under a mutex
+    // and a launch waits (on the device, by event) for the previous launch of this kernel on the same GPU.
+    static std::mutex poolMutex;
     static uint32_t* ovf[16] = {};
     static size_t ovfBytes[16] = {};
+    static hipEvent_t lastDone[16] = {};
+    std::lock_guard<std::mutex> lock(poolMutex);
     int dev = 0;
     if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
     const size_t need = (size_t)grid * NS * kWideStack * 4;
     if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
     if (need > ovfBytes[dev]) {
+        if ((e = hipDeviceSynchronize()) != hipSuccess) return e;      // nothing may still use the old area
         if (ovf[dev]) (void)hipFree(ovf[dev]);
         ovf[dev] = nullptr; ovfBytes[dev] = 0;
         if ((e = hipMalloc(reinterpret_cast<void**>(&ovf[dev]), need)) != hipSuccess) return e;
         ovfBytes[dev] = need;
     }
+    if (!lastDone[dev]) { if ((e = hipEventCreateWithFlags(&lastDone[dev], hipEventDisableTiming)) != hipSuccess) return e; }
+    else if ((e = hipStreamWaitEvent(stream, lastDone[dev], 0)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(tracePool<SPH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     hipLaunchKernelGGL((tracePool<SPH>), dim3(grid), dim3(P.poolBlock), lds, stream, P, ovf[dev]);
+    if ((e = hipEventRecord(lastDone[dev], stream)) != hipSuccess) return e;
 #ifdef YART_STEP_STATS
     uint32_t st[12];
     if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(st + 2, P.workCounter + 9, 10 * 4, hipMemcpyDeviceToHost) == hipSuccess && P.n > 1000000)
